@@ -1,0 +1,202 @@
+/*
+ * asd_hip.h -- C ABI of libasd_hip.so: the MI355X (gfx950) draft-verify / accept /
+ * optimal-stopping hot path behind the reference's Python API.
+ *
+ * The reference (sa2shun/adaptive-speculative-decoding) is 100 % Python and has no FFI of its
+ * own, so every entry point below cites the reference *Python* symbol whose
+ * arithmetic it replaces.  The reference-side binding a maintainer would add is a ctypes stub;
+ * it is shown in INTEGRATION.md and shipped as asd_amd/_binding.py.
+ *
+ * Conventions
+ *   - every function returns an asd_status (0 = ok, negative = error); nothing throws, nothing
+ *     allocates device memory, nothing synchronises the device or the stream;
+ *   - every pointer except the ones marked "host" is a DEVICE pointer on the current HIP
+ *     device; `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - there is no CPU mode: the library only launches gfx950 kernels.  The CPU restatement
+ *     lives in oracle/ and is test infrastructure only.
+ *   - rows: a "row" is one verified position r = b*K + k of sequence b, draft position k.
+ */
+#ifndef ASD_HIP_H
+#define ASD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASD_VERSION_MAJOR 0
+#define ASD_VERSION_MINOR 1
+#define ASD_VERSION_PATCH 0
+
+typedef enum asd_status {
+    ASD_OK = 0,
+    ASD_ERR_INVALID_ARG = -1, /* NULL pointer, negative size, length mismatch (reference: ValueError, dp_solver.py:34-35) */
+    ASD_ERR_UNSUPPORTED = -2, /* K > 64, L > 16, unknown dtype, ... */
+    ASD_ERR_WORKSPACE = -3,   /* workspace too small or misaligned */
+    ASD_ERR_HIP = -4,         /* a HIP runtime call failed (launch error, no device) */
+    ASD_ERR_ALIGNMENT = -5    /* an operand pointer violates its element alignment */
+} asd_status;
+
+typedef enum asd_dtype {
+    ASD_DTYPE_F32 = 0,
+    ASD_DTYPE_BF16 = 1,
+    ASD_DTYPE_F16 = 2
+} asd_dtype;
+
+/* limits enforced by the launchers */
+#define ASD_MAX_DRAFT_LEN 64   /* K: one ballot word per sequence */
+#define ASD_MAX_STAGES 16      /* L: tiers in the DP rule */
+#define ASD_MAX_SPLITS 64      /* vocab splits per row inside one launch */
+#define ASD_MAX_MLP_DIM 1024   /* predictor input / hidden width */
+#define ASD_NUM_LP_STATS 5     /* mean, std, min, q25, median */
+
+/* version = major*10000 + minor*100 + patch */
+int asd_version(void);
+/* host: static string for a status code */
+const char* asd_status_string(int status);
+/* host: number of compute units of HIP device `device` (cached); <0 = asd_status */
+int asd_device_cu_count(int device);
+
+/* ------------------------------------------------------------------------------------------
+ * A5 / A6  token-level verify + accept.
+ *
+ * Replaces the per-token loop `probs = F.softmax(score[0]); logprob = torch.log(probs[token_id])`
+ * of src/training/generate_training_data.py:128-136 (one token at a time, 3 launches + a D2H
+ * sync each) with ONE streaming pass over [B,K,V], and adds the speculative-sampling test the
+ * north star names (no reference symbol exists for it):
+ *
+ *   lse[b,k]    = log sum_v exp(logits[b,k,v])
+ *   lp_t[b,k]   = logits[b,k,tok[b,k]] - lse[b,k]          (tok outside [0,V) => -inf)
+ *   accept[b,k] = log(u[b,k]) <= lp_t[b,k] - lp_d[b,k]     (== u <= min(1, p_t/p_d))
+ *   bits[b]     = sum_k accept[b,k] << k
+ *   n_acc[b]    = number of leading 1 bits of bits[b] (length of the accepted prefix)
+ *
+ * logits: [B*K rows][V] of `dtype`, consecutive rows `ld_row` ELEMENTS apart (ld_row >= V).
+ * workspace: >= asd_verify_accept_workspace_bytes(B,K,V,dtype) bytes, 256-byte aligned, and
+ * zero-initialised ONCE with asd_workspace_init before its first use; the kernel leaves it
+ * ready for the next call (tickets are reset by the last arriver), so one workspace serves any
+ * number of stream-ordered calls.  Two calls that may run CONCURRENTLY need two workspaces.
+ * ---------------------------------------------------------------------------------------- */
+size_t asd_verify_accept_workspace_bytes(int B, int K, int V, int dtype);
+int asd_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+
+int asd_verify_accept(const void* logits, int dtype, int64_t ld_row,
+                      const int32_t* tok /*[B,K]*/, const float* lp_draft /*[B,K]*/,
+                      const float* u /*[B,K]*/, int B, int K, int V,
+                      float* lp_target /*[B,K] out*/, uint8_t* accept /*[B,K] out*/,
+                      int32_t* n_acc /*[B] out*/, uint64_t* accept_bits /*[B] out, may be NULL*/,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same kernel with the launch geometry chosen by the caller (bench / tuning sweeps):
+ * splits in [1,ASD_MAX_SPLITS] workgroups per row, threads in {256,512,1024},
+ * unroll in {2,4,8} 16-byte loads in flight per lane, nontemporal 0/1.
+ * A 0 for any of them means "use the heuristic". */
+int asd_verify_accept_tuned(const void* logits, int dtype, int64_t ld_row,
+                            const int32_t* tok, const float* lp_draft, const float* u,
+                            int B, int K, int V,
+                            float* lp_target, uint8_t* accept, int32_t* n_acc,
+                            uint64_t* accept_bits,
+                            void* workspace, size_t workspace_bytes, void* stream,
+                            int splits, int threads, int unroll, int nontemporal);
+
+/* Vocab-sharded target (lm_head split over ranks): each rank reduces its [B,K,V_shard] slice,
+ * whose first column is global vocab id `v_offset`, to msg[b,k,:] = (m, s, g):
+ *   m = max_v x,  s = sum_v exp(x - m),  g = x[tok - v_offset] if the token is in this shard
+ *   else -inf.   One all-gather of msg ([B,K,3] f32 per rank) is the only exchange step. */
+int asd_lse_partial(const void* logits_shard, int dtype, int64_t ld_row,
+                    const int32_t* tok /*[B,K] GLOBAL ids*/, int B, int K, int V_shard,
+                    int64_t v_offset, float* msg /*[B,K,3] out*/,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Combine the all-gathered partials (fixed shard order => identical on every rank) and run the
+ * acceptance test.  msg_all: [n_shards][B][K][3]. */
+int asd_accept_from_partials(const float* msg_all, int n_shards,
+                             const float* lp_draft, const float* u, int B, int K,
+                             float* lp_target, uint8_t* accept, int32_t* n_acc,
+                             uint64_t* accept_bits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A7  log-prob statistics: features [5..9] of extract_features,
+ * src/training/generate_training_data.py:166-175 -- np.mean, np.std (population), np.min,
+ * np.percentile(.,25) (linear interpolation), np.median, all in float64 like numpy.
+ * lp: [B rows][<=K valid] f32, rows `ld` elements apart; n_valid[b] in [0,K] (NULL => K).
+ * n_valid[b]==0 => five zeros (reference: `features.extend([0.0]*5)`, :174-175).
+ * stats: [B,5] f64.
+ * ---------------------------------------------------------------------------------------- */
+int asd_logprob_stats(const float* lp, int64_t ld, const int32_t* n_valid, int B, int K,
+                      double* stats /*[B,5] out*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A8  MinimalQualityPredictor.forward in eval mode, src/minimal_adaptive_decoder.py:38-49:
+ *   score = sigmoid(W2 . relu(W1 x + b1) + b2)          (Dropout(0.1) == identity)
+ * packed_w (f32): W1T [in_dim][hidden] (= net.0.weight transposed), b1 [hidden],
+ *                 W2 [hidden] (= net.3.weight[0]), b2 [1]   => in_dim*hidden + 2*hidden + 1.
+ * asd_mlp_pack_weights (host pointers) builds that buffer from the state_dict tensors.
+ * ---------------------------------------------------------------------------------------- */
+size_t asd_mlp_packed_floats(int in_dim, int hidden);
+int asd_mlp_pack_weights(const float* w1 /*host [hidden,in_dim]*/, const float* b1 /*host*/,
+                         const float* w2 /*host [hidden]*/, const float* b2 /*host [1]*/,
+                         int in_dim, int hidden, float* packed /*host out*/);
+int asd_mlp_predict(const float* x /*[B rows][in_dim], rows ldx apart*/, int64_t ldx,
+                    const float* packed_w, int B, int in_dim, int hidden,
+                    float* score /*[B] out*/, void* stream);
+
+/* A11  stop test of MinimalAdaptiveDecoder.decode, src/minimal_adaptive_decoder.py:153-164:
+ *   stage[b] = first s in [0,L) with (double)score[b] >= theta[s], or s == L-1. */
+int asd_threshold_stop(const float* score /*[B]*/, const double* theta /*[L]*/, int B, int L,
+                       int32_t* stage /*[B] out*/, void* stream);
+
+/* A2  bayesian_adjustment, src/algorithms/dp_solver.py:106-130 (f64, no FMA contraction):
+ *   a = n_obs*p + alpha;  b = n_obs*(1-p) + beta;  out = a / (a + b) */
+int asd_bayes_adjust(const double* p /*[n]*/, int64_t n_obs, double alpha, double beta, int n,
+                     double* out /*[n] out*/, void* stream);
+
+/* A1  optimal_stopping_rule, src/algorithms/dp_solver.py:12-71, batched over B requests.
+ *   p: [B,L] f64; C: [L] f64 shared by the batch; lam f64.
+ *   risk_adjustment != 0 applies bayesian_adjustment(p, n_obs=100, alpha, beta) first (:38-39).
+ *   k_star: [B] i32; J: [B,L+1] f64 (may be NULL).  Bit-exact with CPython float arithmetic. */
+int asd_optimal_stopping(const double* p, const double* C, double lam, int B, int L,
+                         int risk_adjustment, double alpha, double beta,
+                         int32_t* k_star, double* J, void* stream);
+
+/* A3  compute_expected_cost, dp_solver.py:74-103: sum(C[:k+1]) + lam*(1 - prod(p[:k+1])),
+ * for a per-request stopping stage k[b] in [0,L). */
+int asd_expected_cost(const double* p /*[B,L]*/, const double* C /*[L]*/, double lam,
+                      const int32_t* k /*[B]*/, int B, int L, double* cost /*[B] out*/,
+                      void* stream);
+
+/* A10  OptimalStoppingTheory.derive_optimal_policy, src/theory/optimal_stopping.py:45-82
+ * (+ _compute_improvement_probability :84-91).  HOST pointers: an O(n) f64 recursion run once
+ * per set_lambda; theta[n] (theta[n-1] = 0), V[n+1] (may be NULL). */
+int asd_derive_thresholds(const double* q, const double* c, int n, double lam,
+                          double* theta, double* V);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused post-verify epilogue (first form): one launch per tier step does
+ *   stats   = logprob_stats(lp[b, :n_valid[b]])                      (A7)
+ *   x       = feat[b,:] with x[stats_col .. stats_col+5) = (f32)stats (stats_col < 0: untouched)
+ *   score   = mlp(x)                                                  (A8)
+ *   p_adj   = risk_adjustment ? bayes(score, n_obs, alpha, beta) : score   (A2, pipeline.py:234-238)
+ *   p_hist[b, stage_idx] = p_adj            (p_hist: [B,L] f64, columns < stage_idx are inputs)
+ *   k_star  = optimal_stopping_rule(p_hist[b,:n_dp], C[:n_dp], lam)   (A1)  n_dp = prefix ? stage_idx+1 : L
+ *             (columns > stage_idx are read as given: the caller pre-fills priors, 1.0 for the last)
+ *   theta != NULL additionally:  thr_stop[b] = (double)score >= theta[stage_idx] || stage_idx == L-1   (A11)
+ *   stop[b] = (k_star == stage_idx)
+ * Outputs that are NULL are skipped.  feat rows are ldf apart and are NOT modified.
+ * ---------------------------------------------------------------------------------------- */
+int asd_predictor_stop(const float* lp /*[B,K]*/, int64_t ld_lp, const int32_t* n_valid, int K,
+                       const float* feat /*[B,in_dim]*/, int64_t ldf, int stats_col,
+                       const float* packed_w, int in_dim, int hidden,
+                       int risk_adjustment, int64_t n_obs, double alpha, double beta,
+                       double* p_hist /*[B,L] in/out*/, const double* C /*[L]*/, double lam,
+                       int L, int stage_idx, int prefix_rule,
+                       const double* theta /*[L] or NULL*/, int B,
+                       float* score /*[B]*/, int32_t* k_star /*[B]*/, uint8_t* stop /*[B]*/,
+                       uint8_t* thr_stop /*[B]*/, double* stats /*[B,5]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASD_HIP_H */

@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REFERENCE's own files.  Dev-container only.
+
+Runs the reference source unmodified: each needed file under /root/reference/src is loaded by
+path (importlib.util.spec_from_file_location) with empty synthetic parent packages, because
+`import src` itself raises TypeError at src/core/interfaces.py:466.  The one
+function whose module cannot be imported (extract_features: its module needs the absent
+`evaluate` package) is compiled from its own FunctionDef node of the reference file's AST.
+
+Nothing here travels to the GPU box except the fixtures it writes (data: inputs + expected
+outputs).  Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+"""
+from __future__ import annotations
+
+import ast
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("ASD_REFERENCE", "/root/reference")
+SRC = os.path.join(REF, "src")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+sys.dont_write_bytecode = True
+
+
+def _load(name: str, path: str):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    for pkg in ("src", "src.theory", "src.algorithms"):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    dp = _load("src.algorithms.dp_solver", os.path.join(SRC, "algorithms", "dp_solver.py"))
+    th = _load("src.theory.optimal_stopping", os.path.join(SRC, "theory", "optimal_stopping.py"))
+    mad = _load("src.minimal_adaptive_decoder", os.path.join(SRC, "minimal_adaptive_decoder.py"))
+    return dp, th, mad
+
+
+def load_extract_features():
+    """Compile ONLY the FunctionDef `extract_features` (generate_training_data.py:148-205)."""
+    path = os.path.join(SRC, "training", "generate_training_data.py")
+    with open(path, "r") as f:
+        tree = ast.parse(f.read(), filename=path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "extract_features")
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"np": np, "List": list, "Dict": dict}
+    from typing import Dict, List  # noqa: F401  (annotations are evaluated at def time)
+    ns.update(Dict=Dict, List=List)
+    exec(compile(mod, path, "exec"), ns)
+    return ns["extract_features"]
+
+
+def gen_dp(dp, rng):
+    N = 1600
+    P = np.full((N, 4), np.nan)
+    Cm = np.full((N, 4), np.nan)
+    Ls = np.zeros(N, np.int32)
+    lam = np.zeros(N)
+    risk = np.zeros(N, np.int32)
+    alpha = np.ones(N)
+    beta = np.ones(N)
+    ks = np.zeros(N, np.int32)
+    J = np.full((N, 5), np.nan)
+    cost_sets = [[1.0, 1.6, 4.2, 8.8], [1.0, 2.0, 4.5, 10.0], [1.0, 4.5, 10.0, 20.0]]
+    lam_choices = [0.0, 0.01, 0.1, 0.5, 1.0, 2.0, 5.0, 10.0, 100.0]
+    for i in range(N):
+        L = int(rng.integers(1, 5))
+        mode = i % 8
+        if mode == 0:
+            p = rng.choice([0.0, 0.5, 1.0], size=L)               # ties / degenerate
+        elif mode == 1:
+            p = np.round(rng.uniform(0, 1, L), 2)                 # OptimalStoppingTable keys
+        else:
+            p = rng.uniform(0, 1, L)
+        if mode == 2:
+            p[-1] = 1.0                                           # pipeline.py:241 last stage
+        c = (np.array(cost_sets[i % 3][:L]) if mode != 3 else rng.uniform(0.1, 10, L))
+        la = float(lam_choices[i % len(lam_choices)]) if mode != 4 else float(rng.uniform(0, 20))
+        ra = int(mode == 5)
+        al, be = (float(rng.uniform(0.5, 3)), float(rng.uniform(0.5, 3))) if ra else (1.0, 1.0)
+        k, Jr = dp.optimal_stopping_rule([float(x) for x in p], [float(x) for x in c], la,
+                                         risk_adjustment=bool(ra), alpha=al, beta=be)
+        P[i, :L], Cm[i, :L], Ls[i], lam[i], risk[i], alpha[i], beta[i] = p, c, L, la, ra, al, be
+        ks[i] = k
+        J[i, :L + 1] = Jr
+    # compute_expected_cost on the same cases, at k* and at a random stage
+    kk = np.array([rng.integers(0, Ls[i]) for i in range(N)], np.int32)
+    ec_star = np.array([dp.compute_expected_cost(list(map(float, P[i, :Ls[i]])),
+                                                 list(map(float, Cm[i, :Ls[i]])), float(lam[i]),
+                                                 int(ks[i])) for i in range(N)])
+    ec_rand = np.array([dp.compute_expected_cost(list(map(float, P[i, :Ls[i]])),
+                                                 list(map(float, Cm[i, :Ls[i]])), float(lam[i]),
+                                                 int(kk[i])) for i in range(N)])
+    np.savez(os.path.join(OUT, "dp_rule.npz"), p=P, C=Cm, L=Ls, lam=lam, risk=risk, alpha=alpha,
+             beta=beta, k_star=ks, J=J, k_rand=kk, cost_at_kstar=ec_star, cost_at_krand=ec_rand)
+
+
+def gen_bayes(dp, rng):
+    p = np.concatenate([np.linspace(0, 1, 101), rng.uniform(0, 1, 411)])
+    n_obs = rng.choice([1, 10, 100, 101, 1000, 12345, 10**6], size=p.size).astype(np.int64)
+    al = rng.choice([0.5, 1.0, 2.0, 7.25], size=p.size)
+    be = rng.choice([0.5, 1.0, 2.0, 3.5], size=p.size)
+    out = np.array([dp.bayesian_adjustment(float(p[i]), int(n_obs[i]), float(al[i]), float(be[i]))
+                    for i in range(p.size)])
+    np.savez(os.path.join(OUT, "bayes.npz"), p=p, n_obs=n_obs, alpha=al, beta=be, out=out)
+
+
+def gen_thresholds(th):
+    sets = [([0.7, 0.8, 0.85, 0.9], [1.0, 2.0, 4.5, 10.0]),      # defaults :38-43
+            ([0.7, 0.85, 0.9], [1.0, 4.5, 10.0]),                # 3-tier 7B/32B/72B
+            ([0.55, 0.75, 0.8, 0.95], [1.0, 1.6, 4.2, 8.8]),
+            ([0.6, 0.9], [1.0, 10.0]),
+            ([0.8], [1.0])]
+    lams = [0.0, 0.1, 0.5, 1.0, 2.0, 5.0, 10.0]
+    rows = []
+    for q, c in sets:
+        for la in lams:
+            t = th.OptimalStoppingTheory(th.TheoreticalParameters(
+                n_stages=len(q), quality_bounds=list(q), cost_ratios=list(c), lambda_param=la))
+            pol = t.derive_optimal_policy()
+            rows.append(dict(q=q, c=c, lam=la, theta=[float(pol[s]) for s in range(len(q))]))
+    # defaults path (quality_bounds=None) + misc closed forms
+    t = th.OptimalStoppingTheory(th.TheoreticalParameters(lambda_param=1.0))
+    misc = dict(default_theta=[float(t.derive_optimal_policy()[s]) for s in range(4)],
+                regret_bound={str(T): float(t.compute_regret_bound(T)) for T in (10, 100, 1000, 12345)},
+                sample_complexity=int(t.sample_complexity()))
+    ra = th.RegretAnalyzer(t)
+    inst = [(s, d, float(ra.compute_instantaneous_regret(s, d)))
+            for s in range(4) for d in (0.0, 0.29, 0.3, 0.49, 0.5, 0.69, 0.7, 1.0)]
+    misc["instant_regret"] = inst
+    misc["cumulative"] = float(ra.compute_cumulative_regret())
+    misc["average"] = float(ra.compute_average_regret())
+    misc["tve"] = {k: float(v) for k, v in ra.theoretical_vs_empirical().items()}
+    with open(os.path.join(OUT, "thresholds.json"), "w") as f:
+        json.dump(dict(rows=rows, misc=misc), f, indent=1)
+
+
+def gen_predictor(th, mad, rng):
+    torch.manual_seed(20251004)
+    pred = mad.MinimalQualityPredictor().eval()          # parity is eval mode
+    sd = {k: v.detach().numpy().copy() for k, v in pred.state_dict().items()}
+    X = rng.standard_normal((256, 64)).astype(np.float32)
+    X[:128, 3:] = 0.0                                     # A9 layout: only 3 live columns
+    X[:128, :3] = np.abs(X[:128, :3])
+    X[250:] *= 20.0                                       # saturating rows
+    with torch.no_grad():
+        scores = pred(torch.from_numpy(X)).numpy().reshape(-1).copy()
+        one_by_one = np.array([pred(torch.from_numpy(X[i]).unsqueeze(0)).item() for i in range(256)])
+    picks = {}
+    for la in (0.0, 0.01, 0.05, 0.1, 0.5, 1.0):
+        t = th.OptimalStoppingTheory(th.TheoreticalParameters(lambda_param=la))
+        thr = t.derive_optimal_policy()
+        n_models = 4
+        sel = []
+        for i in range(256):                              # minimal_adaptive_decoder.py:153-164
+            q = float(one_by_one[i])
+            chosen = None
+            for stage_idx in range(n_models):
+                threshold = thr.get(stage_idx, 0.0)
+                if q >= threshold or stage_idx == n_models - 1:
+                    chosen = stage_idx
+                    break
+            sel.append(chosen)
+        picks[str(la)] = dict(theta=[float(thr[s]) for s in range(4)], stage=sel)
+    np.savez(os.path.join(OUT, "predictor.npz"), w1=sd["net.0.weight"], b1=sd["net.0.bias"],
+             w2=sd["net.3.weight"], b2=sd["net.3.bias"], X=X, scores=scores,
+             scores_one_by_one=one_by_one.astype(np.float64))
+    with open(os.path.join(OUT, "threshold_picks.json"), "w") as f:
+        json.dump(picks, f)
+
+    # A9: MinimalQualityPredictor.extract_features with a stand-in tokenizer (the real one is a
+    # fetch-by-name loader, unavailable offline): token ids are DATA supplied by the fixture.
+    class _Tok:
+        def __init__(self, ids):
+            self.ids = ids
+
+        def encode(self, prompt, return_tensors="pt"):
+            return torch.tensor([self.ids], dtype=torch.int64)
+
+    a9 = []
+    prompts = ["", "hello", "What is the capital of France?", "a b c d e f g " * 30,
+               "Explain the proof of the Cauchy-Schwarz inequality step by step " * 12]
+    for i, pr in enumerate(prompts):
+        T = [0, 1, 7, 300, 700][i]
+        ids = [int(x) for x in rng.integers(0, max(2, T // 2 + 1), size=T)]
+        if T == 0:
+            # length==0 branch: entropy = 0 (:60); torch.unique of an empty tensor is fine
+            pass
+        feats = pred.extract_features(pr, _Tok(ids)).numpy().astype(np.float32)
+        a9.append(dict(prompt=pr, ids=ids, features=[float(x) for x in feats]))
+    # A12: _estimate_difficulty / _compute_regret (pure functions of their arguments)
+    cfg = {"models": {"stages": [
+        {"size_label": "7b", "theoretical_quality": 0.7, "relative_cost": 1.0},
+        {"size_label": "14b", "theoretical_quality": 0.8, "relative_cost": 2.0},
+        {"size_label": "32b", "theoretical_quality": 0.85, "relative_cost": 4.5},
+        {"size_label": "72b", "theoretical_quality": 0.9, "relative_cost": 10.0}]}}
+    fake = types.SimpleNamespace(config=cfg)
+    a12 = []
+    texts = ["hi", "why is the sky blue?", "how do transformers implement attention? why?",
+             "Please characterize the asymptotically optimal stopping thresholds " * 4,
+             "Explain, how? why? internationalization considerations notwithstanding " * 9]
+    for tx in texts:
+        d = mad.MinimalAdaptiveDecoder._estimate_difficulty(fake, tx)
+        regs = [float(mad.MinimalAdaptiveDecoder._compute_regret(fake, s, d)) for s in range(4)]
+        a12.append(dict(prompt=tx, difficulty=float(d), regret=regs))
+    with open(os.path.join(OUT, "decoder_misc.json"), "w") as f:
+        json.dump(dict(a9=a9, a12=a12, config=cfg), f, indent=1)
+
+
+def gen_features_a7(rng):
+    extract_features = load_extract_features()
+    prompts = ["What is 2+2?", "def f(x):\n    return x*2  # explain", "why how when where which what",
+               "import numpy as np; a<b", "Translate this sentence into French please", ""]
+    outputs = ["4", "It doubles x . It doubles x .", "because " * 17, "ok", "Bonjour le monde " * 5, ""]
+    N = 96
+    LP = np.zeros((N, 128), np.float64)
+    nv = np.zeros(N, np.int32)
+    F = np.zeros((N, 64), np.float64)
+    meta = []
+    for i in range(N):
+        n = int(rng.choice([0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 64, 100, 127, 128]))
+        lp32 = (-np.abs(rng.standard_normal(n)) * rng.choice([0.1, 1.0, 5.0])).astype(np.float32)
+        if i % 11 == 0 and n > 2:
+            lp32[1] = lp32[0]                                  # duplicates (tie handling in sort)
+        lp = [float(x) for x in lp32]                          # .item() of an f32 tensor (:133)
+        pi, oi, st = i % len(prompts), (i * 5) % len(outputs), i % 4
+        md = {"logprobs": lp, "generation_time": float(rng.uniform(0.0005, 3.0)),
+              "completion_tokens": n}
+        F[i] = extract_features(prompts[pi], outputs[oi], md, st)
+        LP[i, :n] = lp
+        nv[i] = n
+        meta.append(dict(prompt=prompts[pi], output=outputs[oi], stage_id=st,
+                         generation_time=md["generation_time"], completion_tokens=n))
+    np.savez(os.path.join(OUT, "features_a7.npz"), logprobs=LP, n_valid=nv, features=F)
+    with open(os.path.join(OUT, "features_a7_meta.json"), "w") as f:
+        json.dump(meta, f)
+
+
+def gen_logprob_idiom(rng):
+    """generate_training_data.py:128-136 run with torch exactly as written, on small scores."""
+    import torch.nn.functional as F
+    R, V = 24, 1000
+    scores = (rng.standard_normal((R, V)) * 4).astype(np.float32)
+    scores[3, 100:900] = -np.inf                                # top-p style masked vocab
+    toks = rng.integers(0, V, size=R).astype(np.int64)
+    toks[3] = 5
+    toks[4] = int(np.argmax(scores[4]))
+    out32 = []
+    for i in range(R):
+        score = torch.from_numpy(scores[i:i + 1])               # outputs.scores[i]: [1, V]
+        probs = F.softmax(score[0], dim=-1)
+        token_id = torch.tensor(toks[i])
+        out32.append(torch.log(probs[token_id]).item())
+    np.savez(os.path.join(OUT, "logprob_idiom.npz"), scores=scores, tok=toks.astype(np.int32),
+             logprob=np.array(out32, np.float64))
+
+
+def gen_a4(dp, rng):
+    tab = dp.OptimalStoppingTable(lambda_values=[0.1, 1.0, 10.0], num_stages=4)
+    grid = [[a, b, c, 1.0] for a in (0.2, 0.5, 0.8) for b in (0.3, 0.6, 0.9) for c in (0.4, 0.7)]
+    cost = [1.0, 1.6, 4.2, 8.8]
+    tab.precompute(cost, grid)
+    queries = [([0.2, 0.3, 0.4, 1.0], 1.0), ([0.204, 0.296, 0.401, 1.0], 0.9), ([0.5, 0.9, 0.7, 1.0], 7.0),
+               ([0.33, 0.33, 0.33, 1.0], 1.0), ([0.33, 0.66], 0.2), ([0.8, 0.9, 0.7, 1.0], 0.1)]
+    look = [dict(p=p, lam=la, k=int(tab.lookup(p, la)), k_nofallback=int(tab.lookup(p, la, False)))
+            for p, la in queries]
+    ad = dp.AdaptiveStopping(initial_lambda=0.7, confidence_level=0.1)
+    upd = []
+    for i in range(60):
+        st, q, lat = int(rng.integers(0, 4)), float(rng.uniform(0, 1)), float(rng.uniform(50, 4000))
+        ad.update_statistics(st, q, lat)
+        upd.append([st, q, lat])
+    bounds = [[float(x) for x in ad.get_confidence_bounds(s)] for s in range(4)]
+    explore = [bool(ad.should_explore(s)) for s in range(4)]
+    fresh = dp.AdaptiveStopping()
+    with open(os.path.join(OUT, "a4_table_adaptive.json"), "w") as f:
+        json.dump(dict(cost=cost, grid=grid, lambdas=[0.1, 1.0, 10.0], lookups=look, updates=upd,
+                       counts=[float(x) for x in ad.stage_counts],
+                       rewards=[float(x) for x in ad.stage_rewards], bounds=bounds, explore=explore,
+                       fresh_bounds=[str(x) for x in fresh.get_confidence_bounds(0)],
+                       fresh_explore=bool(fresh.should_explore(2))), f, indent=1)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    dp, th, mad = load_reference()
+    rng = np.random.default_rng(1234)
+    gen_dp(dp, rng)
+    gen_bayes(dp, rng)
+    gen_thresholds(th)
+    gen_predictor(th, mad, rng)
+    gen_features_a7(rng)
+    gen_logprob_idiom(rng)
+    gen_a4(dp, rng)
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()

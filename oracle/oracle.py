@@ -1,0 +1,313 @@
+"""CPU oracle for the hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and
+only as the checker / timed CPU baseline.  Nothing under adaptive-speculative-decoding_amd/ imports
+it; the product path is libasd_hip.so and fails loudly without it.
+
+Two layers:
+  * `lib`  -- ctypes view of oracle/_build/libasd_oracle.so (asd_oracle.c, plain C, f64 where the
+              reference is CPython float arithmetic);
+  * `py_*` -- pure-Python/numpy restatements that follow the reference line by line; they are
+              slow and are used on small cases to cross-check the C restatement.
+
+Pinning (tests/test_oracle_golden.py): every function with a reference symbol is checked against
+tests/golden/*.npz, produced by oracle/gen_golden.py from the reference's own files.  The
+token-level accept test (A5) has no reference symbol: PARITY UNPINNED for it.
+All citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libasd_oracle.so")
+
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+
+
+def build(force: bool = False) -> str:
+    """Compile asd_oracle.c with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "asd_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------- bf16 / f16 helpers
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even f32 -> bf16 bit pattern (uint16); NaN stays NaN."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    rounded = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    nan = np.isnan(x)
+    if nan.any():
+        rounded = np.where(nan, np.uint16(0x7FC0), rounded)
+    return rounded
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def logits_as_f32(logits: np.ndarray, dtype: int) -> np.ndarray:
+    if dtype == DT_F32:
+        return np.asarray(logits, dtype=np.float32)
+    if dtype == DT_BF16:
+        return bf16_bits_to_f32(logits)
+    return np.asarray(logits).view(np.float16).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- A5 / A6
+def verify_accept(logits: np.ndarray, dtype: int, tok, lp_d, u, B: int, K: int, V: int,
+                  ld_row: Optional[int] = None, n_threads: int = 1):
+    """A5 (+A6).  logits: uint16 bit patterns for bf16/f16, float32 for f32; shape [B*K, ld_row].
+
+    Returns dict(lp_t f32[B,K], lp_t64 f64[B,K], accept u8[B,K], n_acc i32[B], bits u64[B],
+    margin f64[B,K])."""
+    lib = _load()
+    logits = np.ascontiguousarray(logits)
+    if ld_row is None:
+        ld_row = V
+    assert logits.size >= (B * K - 1) * ld_row + V if B * K > 0 else True
+    tok = _c(tok, np.int32).reshape(-1)
+    lp_d = _c(lp_d, np.float32).reshape(-1)
+    u = _c(u, np.float32).reshape(-1)
+    lp_t = np.empty(B * K, np.float32)
+    lp_t64 = np.empty(B * K, np.float64)
+    margin = np.empty(B * K, np.float64)
+    acc = np.empty(B * K, np.uint8)
+    n_acc = np.empty(B, np.int32)
+    bits = np.empty(B, np.uint64)
+    rc = lib.oracle_verify_accept(_p(logits), C.c_int(dtype), C.c_int64(ld_row), _p(tok), _p(lp_d),
+                                  _p(u), C.c_int(B), C.c_int(K), C.c_int(V), _p(lp_t), _p(acc),
+                                  _p(n_acc), _p(bits), _p(lp_t64), _p(margin), C.c_int(n_threads))
+    if rc != 0:
+        raise ValueError(f"oracle_verify_accept rc={rc}")
+    return dict(lp_t=lp_t.reshape(B, K), lp_t64=lp_t64.reshape(B, K), accept=acc.reshape(B, K),
+                n_acc=n_acc, bits=bits, margin=margin.reshape(B, K))
+
+
+def lse_partial(logits: np.ndarray, dtype: int, tok, B: int, K: int, V_shard: int, v_offset: int,
+                ld_row: Optional[int] = None) -> np.ndarray:
+    lib = _load()
+    logits = np.ascontiguousarray(logits)
+    if ld_row is None:
+        ld_row = V_shard
+    tok = _c(tok, np.int32).reshape(-1)
+    msg = np.empty((B, K, 3), np.float64)
+    rc = lib.oracle_lse_partial(_p(logits), C.c_int(dtype), C.c_int64(ld_row), _p(tok), C.c_int(B),
+                                C.c_int(K), C.c_int(V_shard), C.c_int64(v_offset), _p(msg))
+    if rc != 0:
+        raise ValueError(rc)
+    return msg
+
+
+def py_token_logprob_reference_idiom(score_row_f32: np.ndarray, token_id: int) -> float:
+    """generate_training_data.py:131-133 restated with numpy in the row's own precision:
+    probs = softmax(score[0]); logprob = log(probs[token_id])."""
+    x = np.asarray(score_row_f32)
+    e = np.exp(x - x.max())
+    probs = e / e.sum()
+    return float(np.log(probs[token_id]))
+
+
+def py_verify_accept(logits_f32: np.ndarray, tok, lp_d, u):
+    """numpy f64 restatement of A5 on [B,K,V] f32 logits (small cases)."""
+    x = np.asarray(logits_f32, dtype=np.float64)
+    B, K, V = x.shape
+    tok = np.asarray(tok).reshape(B, K)
+    with np.errstate(all="ignore"):
+        m = x.max(axis=-1)
+        s = np.exp(x - m[..., None]).sum(axis=-1)
+        lse = np.where(np.isneginf(m), -np.inf, m + np.log(s))
+        inside = (tok >= 0) & (tok < V)
+        g = np.where(inside, np.take_along_axis(x, np.clip(tok, 0, V - 1)[..., None], -1)[..., 0],
+                     -np.inf)
+        lp = g - lse
+        uu = np.asarray(u, dtype=np.float32).reshape(B, K).astype(np.float64)
+        lu = np.where(uu > 0, np.log(np.where(uu > 0, uu, 1.0)), np.where(uu == 0, -np.inf, np.nan))
+        acc = lu <= (lp - np.asarray(lp_d, dtype=np.float32).reshape(B, K).astype(np.float64))
+    n_acc = np.array([int(np.argmin(np.append(a, False))) for a in acc], dtype=np.int32)
+    return lp, acc.astype(np.uint8), n_acc
+
+
+# ----------------------------------------------------------------------------- A7
+def logprob_stats(lp, n_valid=None, K: Optional[int] = None) -> np.ndarray:
+    lib = _load()
+    lp = _c(lp, np.float32)
+    if lp.ndim == 1:
+        lp = lp[None, :]
+    B, ld = lp.shape
+    if K is None:
+        K = ld
+    nv = None if n_valid is None else _c(n_valid, np.int32)
+    out = np.empty((B, 5), np.float64)
+    lib.oracle_logprob_stats(_p(lp), C.c_int64(ld), _p(nv), C.c_int(B), C.c_int(K), _p(out))
+    return out
+
+
+def py_logprob_stats(logprobs: Sequence[float]) -> List[float]:
+    """generate_training_data.py:166-175 verbatim in behaviour (numpy does the arithmetic)."""
+    if len(logprobs):
+        return [float(np.mean(logprobs)), float(np.std(logprobs)), float(np.min(logprobs)),
+                float(np.percentile(logprobs, 25)), float(np.median(logprobs))]
+    return [0.0] * 5
+
+
+# ----------------------------------------------------------------------------- A8 / A11
+def mlp_predict(x, w1, b1, w2, b2) -> np.ndarray:
+    lib = _load()
+    x = _c(x, np.float32)
+    if x.ndim == 1:
+        x = x[None, :]
+    w1 = _c(w1, np.float32)
+    hidden, in_dim = w1.shape
+    b1 = _c(b1, np.float32).reshape(-1)
+    w2 = _c(w2, np.float32).reshape(-1)
+    b2 = _c(b2, np.float32).reshape(-1)
+    B = x.shape[0]
+    out = np.empty(B, np.float32)
+    lib.oracle_mlp_predict(_p(x), C.c_int64(x.shape[1]), _p(w1), _p(b1), _p(w2), _p(b2), C.c_int(B),
+                           C.c_int(in_dim), C.c_int(hidden), _p(out))
+    return out
+
+
+def threshold_stop(score, theta) -> np.ndarray:
+    lib = _load()
+    score = _c(score, np.float32).reshape(-1)
+    theta = _c(theta, np.float64).reshape(-1)
+    out = np.empty(score.size, np.int32)
+    lib.oracle_threshold_stop(_p(score), _p(theta), C.c_int(score.size), C.c_int(theta.size), _p(out))
+    return out
+
+
+# ----------------------------------------------------------------------------- A1 / A2 / A3 / A10
+def bayes_adjust(p, n_obs: int, alpha: float = 1.0, beta: float = 1.0) -> np.ndarray:
+    lib = _load()
+    p = _c(p, np.float64).reshape(-1)
+    out = np.empty_like(p)
+    lib.oracle_bayes_adjust(_p(p), C.c_int64(n_obs), C.c_double(alpha), C.c_double(beta),
+                            C.c_int(p.size), _p(out))
+    return out
+
+
+def optimal_stopping(p, Cc, lam: float, risk_adjustment: bool = False, alpha: float = 1.0,
+                     beta: float = 1.0) -> Tuple[np.ndarray, np.ndarray]:
+    lib = _load()
+    p = _c(p, np.float64)
+    if p.ndim == 1:
+        p = p[None, :]
+    B, L = p.shape
+    Cc = _c(Cc, np.float64).reshape(-1)
+    if Cc.size != L:
+        raise ValueError("p and C must have the same length")  # dp_solver.py:34-35
+    k = np.empty(B, np.int32)
+    J = np.empty((B, L + 1), np.float64)
+    rc = lib.oracle_optimal_stopping(_p(p), _p(Cc), C.c_double(lam), C.c_int(B), C.c_int(L),
+                                     C.c_int(int(risk_adjustment)), C.c_double(alpha),
+                                     C.c_double(beta), _p(k), _p(J))
+    if rc != 0:
+        raise ValueError(rc)
+    return k, J
+
+
+def expected_cost(p, Cc, lam: float, k) -> np.ndarray:
+    lib = _load()
+    p = _c(p, np.float64)
+    if p.ndim == 1:
+        p = p[None, :]
+    B, L = p.shape
+    Cc = _c(Cc, np.float64).reshape(-1)
+    k = _c(k, np.int32).reshape(-1)
+    out = np.empty(B, np.float64)
+    lib.oracle_expected_cost(_p(p), _p(Cc), C.c_double(lam), _p(k), C.c_int(B), C.c_int(L), _p(out))
+    return out
+
+
+def derive_thresholds(q, c, lam: float) -> Tuple[np.ndarray, np.ndarray]:
+    lib = _load()
+    q = _c(q, np.float64).reshape(-1)
+    c = _c(c, np.float64).reshape(-1)
+    n = q.size
+    theta = np.empty(n, np.float64)
+    V = np.empty(n + 1, np.float64)
+    rc = lib.oracle_derive_thresholds(_p(q), _p(c), C.c_int(n), C.c_double(lam), _p(theta), _p(V))
+    if rc != 0:
+        raise ValueError(rc)
+    return theta, V
+
+
+# pure-Python restatements (CPython float == IEEE f64, no FMA), used to cross-check the C code
+def py_bayesian_adjustment(p_hat: float, n_obs: int, alpha: float = 1.0, beta: float = 1.0) -> float:
+    """dp_solver.py:106-130."""
+    pa = n_obs * p_hat + alpha
+    pb = n_obs * (1 - p_hat) + beta
+    return pa / (pa + pb)
+
+
+def py_optimal_stopping_rule(p: Sequence[float], Cc: Sequence[float], lam: float,
+                             risk_adjustment: bool = False, alpha: float = 1.0,
+                             beta: float = 1.0) -> Tuple[int, List[float]]:
+    """dp_solver.py:12-71."""
+    if len(p) != len(Cc):
+        raise ValueError("p and C must have the same length")
+    L = len(Cc)
+    if risk_adjustment:
+        p = [py_bayesian_adjustment(pi, 100, alpha, beta) for pi in p]
+    p_bar = [1.0]
+    for i in range(L):
+        p_bar.append(p_bar[-1] * p[i])
+    J = [0.0] * (L + 1)
+    stop = [False] * L
+    for i in reversed(range(L)):
+        a = Cc[i] + lam * (1 - p_bar[i + 1])
+        b = Cc[i] + J[i + 1]
+        if a <= b:
+            stop[i], J[i] = True, a
+        else:
+            stop[i], J[i] = False, b
+    k = next((i for i, s in enumerate(stop) if s), L - 1)
+    return k, J
+
+
+def py_derive_optimal_policy(q: Sequence[float], c: Sequence[float], lam: float) -> List[float]:
+    """optimal_stopping.py:45-82."""
+    n = len(q)
+    V = [0.0] * (n + 1)
+    th = [0.0] * n
+    for s in range(n - 1, -1, -1):
+        r_stop = q[s] - lam * c[s]
+        if s < n - 1:
+            pi = 0.6 * (1 - q[s])
+            r_cont = pi * V[s + 1] + (1 - pi) * r_stop
+        else:
+            r_cont = -math.inf
+        V[s] = max(r_stop, r_cont)
+        th[s] = (V[s + 1] + lam * c[s]) / (1 + lam * (c[s + 1] - c[s])) if s < n - 1 else 0.0
+    return th

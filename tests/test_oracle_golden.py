@@ -1,0 +1,154 @@
+"""The CPU oracle (oracle/asd_oracle.c + oracle/oracle.py) against the golden vectors generated
+from the reference's own files (oracle/gen_golden.py).  Integer / f64 results: bit-exact.
+f32 predictor scores: 1e-6.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def test_dp_rule_bit_exact(golden):
+    g = golden.npz("dp_rule.npz")
+    N = g["L"].size
+    for L in (1, 2, 3, 4):
+        for risk in (0, 1):
+            idx = np.where((g["L"] == L) & (g["risk"] == risk))[0]
+            if idx.size == 0:
+                continue
+            # group by (C, lam, alpha, beta): the batched oracle shares them across a batch
+            for i in idx:
+                k, J = O.optimal_stopping(g["p"][i, :L], g["C"][i, :L], float(g["lam"][i]),
+                                          bool(risk), float(g["alpha"][i]), float(g["beta"][i]))
+                assert int(k[0]) == int(g["k_star"][i]), i
+                assert J[0].tobytes() == g["J"][i, :L + 1].tobytes(), i
+    assert N >= 1000
+
+
+def test_dp_rule_python_restatement_matches_c(golden):
+    g = golden.npz("dp_rule.npz")
+    for i in range(0, g["L"].size, 7):
+        L = int(g["L"][i])
+        k, J = O.py_optimal_stopping_rule(list(map(float, g["p"][i, :L])), list(map(float, g["C"][i, :L])),
+                                          float(g["lam"][i]), bool(g["risk"][i]), float(g["alpha"][i]),
+                                          float(g["beta"][i]))
+        assert k == int(g["k_star"][i])
+        assert np.array(J).tobytes() == g["J"][i, :L + 1].tobytes()
+
+
+def test_dp_rule_length_mismatch_raises():
+    with pytest.raises(ValueError):
+        O.optimal_stopping([0.5, 0.5], [1.0], 1.0)          # dp_solver.py:34-35
+    with pytest.raises(ValueError):
+        O.py_optimal_stopping_rule([0.5], [1.0, 2.0], 1.0)
+
+
+def test_prefix_rule_always_stops_at_stage0():
+    """optimal_stopping_rule on an L=1 prefix returns k*=0 for every p, lam."""
+    for p0 in (0.0, 0.3, 0.9, 0.999, 1.0):
+        for lam in (0.01, 1.0, 100.0):
+            k, _ = O.optimal_stopping([p0], [1.0], lam)
+            assert int(k[0]) == 0
+
+
+def test_expected_cost_bit_exact(golden):
+    g = golden.npz("dp_rule.npz")
+    for i in range(g["L"].size):
+        L = int(g["L"][i])
+        for kk, want in ((g["k_star"][i], g["cost_at_kstar"][i]), (g["k_rand"][i], g["cost_at_krand"][i])):
+            got = O.expected_cost(g["p"][i, :L], g["C"][i, :L], float(g["lam"][i]), [int(kk)])
+            assert got.tobytes() == np.float64(want).tobytes(), i
+
+
+def test_survey_known_answers():
+    k, J = O.optimal_stopping([.3, .5, .8, 1], [1, 1.6, 4.2, 8.8], 100.0)
+    assert int(k[0]) == 3 and J[0].tolist() == [15.6, 14.6, 13.0, 8.8, 0.0]
+    k, J = O.optimal_stopping([.3, .5, .8, 1], [1, 1.6, 4.2, 8.8], 1.0)
+    assert int(k[0]) == 0 and J[0].tolist() == [1.7, 2.45, 5.08, 8.8, 0.0]
+    assert O.bayes_adjust([0.25], 100, 1, 1)[0] == 0.2549019607843137
+    assert O.bayes_adjust([0.9], 1000, 2, 2)[0] == 0.898406374501992
+    th, _ = O.derive_thresholds([.7, .8, .85, .9], [1, 2, 4.5, 10], 0.1)
+    assert th.tolist() == [0.6363636363636364, 0.48, 0.22580645161290325, 0.0]
+    th, _ = O.derive_thresholds([.7, .8, .85, .9], [1, 2, 4.5, 10], 1.0)
+    assert th.tolist() == [-0.09999999999999998, -0.4714285714285714, -0.7076923076923076, 0.0]
+
+
+def test_bayes_bit_exact(golden):
+    g = golden.npz("bayes.npz")
+    for i in range(g["p"].size):
+        got = O.bayes_adjust([g["p"][i]], int(g["n_obs"][i]), float(g["alpha"][i]), float(g["beta"][i]))
+        assert got[0].tobytes() == g["out"][i].tobytes(), i
+        assert O.py_bayesian_adjustment(float(g["p"][i]), int(g["n_obs"][i]), float(g["alpha"][i]),
+                                        float(g["beta"][i])) == float(g["out"][i])
+
+
+def test_thresholds_bit_exact(golden):
+    g = golden.json("thresholds.json")
+    for row in g["rows"]:
+        th, _ = O.derive_thresholds(row["q"], row["c"], row["lam"])
+        assert th.tolist() == row["theta"], row
+        assert O.py_derive_optimal_policy(row["q"], row["c"], row["lam"]) == row["theta"]
+    th, _ = O.derive_thresholds([0.7, 0.8, 0.85, 0.9], [1.0, 2.0, 4.5, 10.0], 1.0)
+    assert th.tolist() == g["misc"]["default_theta"]
+
+
+def test_predictor_scores(golden):
+    g = golden.npz("predictor.npz")
+    got = O.mlp_predict(g["X"], g["w1"], g["b1"], g["w2"][0], g["b2"])
+    # tolerance: BASELINE.json "stopping scores within 1e-5 fp32"; observed ~1e-7
+    np.testing.assert_allclose(got, g["scores"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got, g["scores_one_by_one"], rtol=0, atol=1e-6)
+
+
+def test_threshold_picks_bit_exact(golden):
+    g = golden.npz("predictor.npz")
+    picks = golden.json("threshold_picks.json")
+    scores = g["scores_one_by_one"].astype(np.float32)   # .item() of the f32 output
+    for lam, rec in picks.items():
+        got = O.threshold_stop(scores, rec["theta"])
+        assert got.tolist() == rec["stage"], lam
+
+
+def test_logprob_stats_against_reference_features(golden):
+    g = golden.npz("features_a7.npz")
+    lp = g["logprobs"].astype(np.float32)                # values are f32-representable by construction
+    assert np.array_equal(lp.astype(np.float64), g["logprobs"])
+    got = O.logprob_stats(lp, g["n_valid"], K=128)
+    want = g["features"][:, 5:10]
+    assert got.tobytes() == want.tobytes()
+    for i in range(0, lp.shape[0], 9):
+        n = int(g["n_valid"][i])
+        assert O.py_logprob_stats([float(x) for x in lp[i, :n]]) == want[i].tolist()
+
+
+def test_token_logprob_matches_reference_idiom(golden):
+    """A6: log(softmax(score)[tok]) as the reference computes it (torch f32) vs the f64 oracle."""
+    g = golden.npz("logprob_idiom.npz")
+    R, V = g["scores"].shape
+    res = O.verify_accept(g["scores"], O.DT_F32, g["tok"], np.zeros(R, np.float32),
+                          np.full(R, 0.5, np.float32), B=R, K=1, V=V)
+    np.testing.assert_allclose(res["lp_t"][:, 0], g["logprob"], rtol=1e-6, atol=1e-5)
+    for i in (0, 3, 4, 11):
+        assert abs(O.py_token_logprob_reference_idiom(g["scores"][i], int(g["tok"][i])) - g["logprob"][i]) < 1e-5
+
+
+def test_verify_accept_c_vs_numpy_small():
+    rng = np.random.default_rng(7)
+    B, K, V = 3, 5, 257
+    x = (rng.standard_normal((B, K, V)) * 4).astype(np.float32)
+    bits = O.f32_to_bf16_bits(x)
+    xf = O.bf16_bits_to_f32(bits).reshape(B, K, V)
+    tok = rng.integers(0, V, (B, K)).astype(np.int32)
+    tok[0, 1] = -1
+    tok[1, 2] = V
+    lp_d = -np.abs(rng.standard_normal((B, K))).astype(np.float32)
+    u = rng.uniform(0, 1, (B, K)).astype(np.float32)
+    u[2, 0] = 0.0
+    res = O.verify_accept(bits.reshape(B * K, V), O.DT_BF16, tok, lp_d, u, B, K, V)
+    lp, acc, n_acc = O.py_verify_accept(xf, tok, lp_d, u)
+    np.testing.assert_allclose(res["lp_t64"], lp, rtol=1e-12, atol=1e-12)
+    assert np.array_equal(res["accept"], acc)
+    assert np.array_equal(res["n_acc"], n_acc)
+    assert res["lp_t"][0, 1] == -np.inf and res["accept"][0, 1] == 0
+    for b in range(B):
+        w = sum(int(res["accept"][b, k]) << k for k in range(K))
+        assert int(res["bits"][b]) == w
