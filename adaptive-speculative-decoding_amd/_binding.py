@@ -1,0 +1,94 @@
+"""ctypes binding of libasd_hip.so (include/asd_hip.h).
+
+This is the whole FFI: plain pointers and sizes, no torch types cross the boundary.  The library
+is loaded from adaptive-speculative-decoding_amd/lib/ (built in-tree by build.py); if it is
+missing or a symbol is absent the import of anything that computes FAILS LOUDLY -- there is no
+CPU or PyTorch fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libasd_hip.so")
+
+ASD_OK = 0
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+MAX_DRAFT_LEN = 64
+MAX_STAGES = 16
+MAX_SPLITS = 64
+MAX_MLP_DIM = 1024
+NUM_LP_STATS = 5
+
+_vp, _i, _i64, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/asd_hip.h declaration by declaration
+SIGNATURES = {
+    "asd_version": (_i, []),
+    "asd_status_string": (C.c_char_p, [_i]),
+    "asd_device_cu_count": (_i, [_i]),
+    "asd_verify_accept_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "asd_workspace_init": (_i, [_vp, _sz, _vp]),
+    "asd_verify_accept": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "asd_verify_accept_tuned": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
+                                     _vp, _i, _i, _i, _i]),
+    "asd_lse_partial": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
+    "asd_accept_from_partials": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
+    "asd_mlp_packed_floats": (_sz, [_i, _i]),
+    "asd_mlp_pack_weights": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "asd_mlp_predict": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp, _vp]),
+    "asd_threshold_stop": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "asd_bayes_adjust": (_i, [_vp, _i64, _d, _d, _i, _vp, _vp]),
+    "asd_optimal_stopping": (_i, [_vp, _vp, _d, _i, _i, _i, _d, _d, _vp, _vp, _vp]),
+    "asd_expected_cost": (_i, [_vp, _vp, _d, _vp, _i, _i, _vp, _vp]),
+    "asd_derive_thresholds": (_i, [_vp, _vp, _i, _d, _vp, _vp]),
+    "asd_predictor_stop": (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d,
+                                _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class AsdError(RuntimeError):
+    """A libasd_hip.so entry point returned a negative asd_status."""
+
+    def __init__(self, fn: str, status: int, text: str):
+        super().__init__(f"{fn} failed: {text} (asd_status {status})")
+        self.status = status
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libasd_hip.so and attach the prototypes.  Raises if the library or a symbol is
+    missing -- the caller must build it (`python adaptive-speculative-decoding_amd/build.py`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `python adaptive-speculative-decoding_amd/build.py` (needs hipcc). "
+                "There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:  # pragma: no cover
+                raise RuntimeError(f"{LIB_PATH} does not export {name}: rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(fn: str, status: int) -> None:
+    if status != ASD_OK:
+        text = load_library().asd_status_string(status).decode()
+        raise AsdError(fn, status, text)

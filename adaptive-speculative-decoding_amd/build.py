@@ -1,0 +1,72 @@
+"""Build libasd_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python adaptive-speculative-decoding_amd/build.py [--force] [--verbose]
+
+Output: adaptive-speculative-decoding_amd/lib/libasd_hip.so (git-ignored, travels with gpurun).
+decision.hip and predictor.hip are compiled with -ffp-contract=off: they restate CPython /
+numpy float64 arithmetic and must round once per operator (see decision_device.hpp).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(os.path.dirname(HERE), "include")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libasd_hip.so")
+
+ARCH = "gfx950"
+COMMON = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden",
+          "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", f"-I{INC}", f"-I{CSRC}"]
+SOURCES = {
+    "api.hip": [],
+    "verify_accept.hip": [],
+    "decision.hip": ["-ffp-contract=off"],
+    "predictor.hip": ["-ffp-contract=off"],
+}
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libasd_hip.so cannot be built (ROCm toolchain missing)")
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers += [os.path.join(INC, "asd_hip.h"), os.path.abspath(__file__)]
+    objs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc, *COMMON, *extra, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

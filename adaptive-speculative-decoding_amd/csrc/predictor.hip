@@ -1,0 +1,359 @@
+// predictor.hip -- stopping-rule quality predictor and its feature epilogue, gfx950.
+// Compiled with -ffp-contract=off (numpy / CPython parity of the f64 parts); the f32 MLP uses
+// explicit fmaf.
+//
+//   A7  log-prob statistics   src/training/generate_training_data.py:166-175  (numpy float64)
+//   A8  MinimalQualityPredictor.forward, eval mode   src/minimal_adaptive_decoder.py:38-49
+//   fused epilogue: stats -> features -> MLP -> Bayes -> DP rule / theta test
+//
+// No MFMA: the predictor is 64*32+32 = 2080 MACs per row; at B = 128 that is 0.27 M
+// MACs, far below one MFMA tile's worth of launch latency.  One wave per row, hidden units on
+// lanes, weights staged once per workgroup in LDS, f32 FMAs in registers.
+
+#include "decision_device.hpp"
+
+#include <math.h>
+
+namespace asd {
+namespace {
+
+constexpr int kStatsMaxK = 1024;     // values per sequence the stats path stages in LDS
+constexpr int kWavesPerBlock = 4;
+constexpr size_t kWeightLdsLimit = 32 * 1024;  // keep every launch under the 64 KiB default LDS window
+constexpr int kFusedMaxK = 128;                   // fused epilogue: the reference caps generations at 128 tokens
+
+// ---- numpy pairwise summation (numpy/_core/src/umath/loops_utils.h.src: pairwise_sum) -----
+// n < 8: sequential from 0; n <= 128: eight interleaved accumulators, fixed tree, sequential
+// tail; n > 128: split at (n/2 rounded down to a multiple of 8).  Recursion unrolled by depth
+// (kStatsMaxK = 128 * 2^3).
+__device__ double np_sum_leaf(const double* a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+}
+__device__ __forceinline__ int np_split(int n) { int h = n / 2; return h - (h % 8); }
+__device__ double np_sum_d1(const double* a, int n) {
+    if (n <= 128) return np_sum_leaf(a, n);
+    const int h = np_split(n);
+    return np_sum_leaf(a, h) + np_sum_leaf(a + h, n - h);
+}
+__device__ double np_sum_d2(const double* a, int n) {
+    if (n <= 128) return np_sum_leaf(a, n);
+    const int h = np_split(n);
+    return np_sum_d1(a, h) + np_sum_d1(a + h, n - h);
+}
+__device__ double np_sum(const double* a, int n) {  // n <= 1024
+    if (n <= 128) return np_sum_leaf(a, n);
+    const int h = np_split(n);
+    return np_sum_d2(a, h) + np_sum_d2(a + h, n - h);
+}
+
+// numpy _lerp (numpy/lib/_function_base_impl.py)
+__device__ __forceinline__ double np_lerp(double a, double b, double t) {
+    const double d = b - a;
+    double r = a + d * t;
+    if (t >= 0.5) r = b - d * (1.0 - t);
+    if (d == 0.0) r = a;
+    return r;
+}
+
+// One wave computes the five statistics of vals[0..n) (f64, in LDS); `sorted` and `sq` are LDS
+// scratch of n doubles each.  Result valid in lane 0.
+__device__ void wave_logprob_stats(double* vals, double* sorted, double* sq, int n, int lane, double (&out)[5]) {
+    if (n <= 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) out[i] = 0.0;             // features.extend([0.0]*5) :174-175
+        return;
+    }
+    // rank sort (stable): every value lands at #{smaller} + #{equal and earlier}
+    for (int i = lane; i < n; i += 64) {
+        const double v = vals[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double w = vals[j];
+            rank += (w < v) || (w == v && j < i);
+        }
+        sorted[rank] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double mean = 0.0;
+    if (lane == 0) mean = np_sum(vals, n) / static_cast<double>(n);          // np.mean :168
+    mean = __shfl(mean, 0, 64);
+    for (int i = lane; i < n; i += 64) {
+        const double t = vals[i] - mean;
+        sq[i] = t * t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+        const double var = np_sum(sq, n) / static_cast<double>(n);            // np.std :169 (population)
+        const double vi = static_cast<double>(n - 1) * 0.25;                  // np.percentile(.,25) :171
+        const int lo = static_cast<int>(floor(vi));
+        const int hi = lo + 1 < n ? lo + 1 : n - 1;
+        out[0] = mean;
+        out[1] = sqrt(var);
+        out[2] = sorted[0];                                                   // np.min :170
+        out[3] = np_lerp(sorted[lo], sorted[hi], vi - static_cast<double>(lo));
+        out[4] = (n & 1) ? sorted[n / 2] : (sorted[n / 2 - 1] + sorted[n / 2]) / 2.0;  // np.median :172
+    }
+}
+
+__global__ __launch_bounds__(64) void k_logprob_stats(const float* __restrict__ lp, int64_t ld,
+                                                      const int32_t* __restrict__ n_valid, int B, int K,
+                                                      double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* vals = reinterpret_cast<double*>(smem);
+    double* sorted = vals + K;
+    double* sq = sorted + K;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    int n = n_valid ? n_valid[b] : K;
+    n = n < 0 ? 0 : (n > K ? K : n);
+    for (int i = lane; i < n; i += 64) vals[i] = static_cast<double>(lp[static_cast<int64_t>(b) * ld + i]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double out[5];
+    wave_logprob_stats(vals, sorted, sq, n, lane, out);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) stats[5 * static_cast<int64_t>(b) + i] = out[i];
+    }
+}
+
+// ---- MLP: one wave per row --------------------------------------------------------------
+// packed: W1T [in][hidden], b1 [hidden], W2 [hidden], b2 [1].  xs: the row, in_dim floats in LDS.
+__device__ __forceinline__ float wave_mlp(const float* __restrict__ w, const float* xs, int in_dim, int hidden,
+                                          int lane) {
+    const float* b1 = w + static_cast<int64_t>(in_dim) * hidden;
+    const float* w2 = b1 + hidden;
+    float z = 0.0f;
+    for (int j = lane; j < hidden; j += 64) {
+        float h = b1[j];
+        for (int i = 0; i < in_dim; ++i) h = fmaf(w[static_cast<int64_t>(i) * hidden + j], xs[i], h);
+        h = fmaxf(h, 0.0f);                                   // ReLU; Dropout(0.1) is identity in eval
+        z = fmaf(w2[j], h, z);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) z += __shfl_xor(z, off, 64);
+    z += w2[hidden];                                          // b2
+    return 1.0f / (1.0f + expf(-z));                          // Sigmoid
+}
+
+__device__ __forceinline__ const float* stage_weights(const float* packed, float* wlds, int n_floats, bool use_lds) {
+    if (!use_lds) return packed;
+    for (int i = threadIdx.x; i < n_floats; i += blockDim.x) wlds[i] = packed[i];
+    __syncthreads();
+    return wlds;
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_mlp_predict(const float* __restrict__ x, int64_t ldx,
+                                                                     const float* __restrict__ packed, int B,
+                                                                     int in_dim, int hidden, int use_lds,
+                                                                     float* __restrict__ score) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* xs = reinterpret_cast<float*>(smem) + wave * in_dim;
+    float* wlds = reinterpret_cast<float*>(smem) + kWavesPerBlock * in_dim;
+    const int n_w = in_dim * hidden + 2 * hidden + 1;
+    const float* w = stage_weights(packed, wlds, n_w, use_lds != 0);
+    for (int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; row < B;
+         row += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+        for (int i = lane; i < in_dim; i += 64) xs[i] = x[row * ldx + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float sc = wave_mlp(w, xs, in_dim, hidden, lane);
+        if (lane == 0) score[row] = sc;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- fused epilogue: one wave per sequence ------------------------------------------------
+struct FusedParams {
+    const float* lp; int64_t ld_lp; const int32_t* n_valid; int K;
+    const float* feat; int64_t ldf; int stats_col;
+    const float* packed; int in_dim, hidden, use_lds;
+    int risk; double n_obs, alpha, beta;
+    double* p_hist; const double* C; double lam; int L, stage_idx, prefix;
+    const double* theta; int B;
+    float* score; int32_t* k_star; uint8_t* stop; uint8_t* thr_stop; double* stats;
+};
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_predictor_stop(const FusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // carve: per-wave doubles [3*K], per-wave floats [in_dim], then shared weights
+    double* dbase = reinterpret_cast<double*>(smem) + static_cast<size_t>(wave) * 3 * p.K;
+    float* fbase = reinterpret_cast<float*>(smem + sizeof(double) * 3 * static_cast<size_t>(p.K) * kWavesPerBlock);
+    float* xs = fbase + wave * p.in_dim;
+    float* wlds = fbase + kWavesPerBlock * p.in_dim;
+    const int n_w = p.in_dim * p.hidden + 2 * p.hidden + 1;
+    const float* w = stage_weights(p.packed, wlds, n_w, p.use_lds != 0);
+
+    for (int b = blockIdx.x * kWavesPerBlock + wave; b < p.B; b += gridDim.x * kWavesPerBlock) {
+        double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        const bool want_stats = p.lp && (p.stats_col >= 0 || p.stats);
+        if (want_stats) {
+            int n = p.n_valid ? p.n_valid[b] : p.K;
+            n = n < 0 ? 0 : (n > p.K ? p.K : n);
+            for (int i = lane; i < n; i += 64) dbase[i] = static_cast<double>(p.lp[static_cast<int64_t>(b) * p.ld_lp + i]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_logprob_stats(dbase, dbase + p.K, dbase + 2 * p.K, n, lane, st);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) st[i] = __shfl(st[i], 0, 64);
+            if (p.stats && lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
+            }
+        }
+        for (int i = lane; i < p.in_dim; i += 64) {
+            float v = p.feat[static_cast<int64_t>(b) * p.ldf + i];
+            const int si = i - p.stats_col;
+            if (want_stats && p.stats_col >= 0 && si >= 0 && si < 5) {
+                v = static_cast<float>(si == 0 ? st[0] : si == 1 ? st[1] : si == 2 ? st[2] : si == 3 ? st[3] : st[4]);
+            }
+            xs[i] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float sc = wave_mlp(w, xs, p.in_dim, p.hidden, lane);
+        if (lane == 0) {
+            if (p.score) p.score[b] = sc;
+            // pipeline.py:225-238: prob = predictor.predict(...); prob = bayesian_adjustment(prob, n_obs, a, b)
+            double prob = static_cast<double>(sc);
+            if (p.risk) prob = bayes_adjust1(prob, p.n_obs, p.alpha, p.beta);
+            if (p.p_hist) {
+                double* ph = p.p_hist + static_cast<int64_t>(b) * p.L;
+                ph[p.stage_idx] = prob;
+                if (p.k_star || p.stop) {
+                    const int n_dp = p.prefix ? p.stage_idx + 1 : p.L;       // pipeline.py:248-256 uses the prefix
+                    double pp[ASD_MAX_STAGES], cc[ASD_MAX_STAGES], J[ASD_MAX_STAGES + 1];
+#pragma unroll
+                    for (int i = 0; i < ASD_MAX_STAGES; ++i) {
+                        if (i < n_dp) { pp[i] = (i == p.stage_idx) ? prob : ph[i]; cc[i] = p.C[i]; }
+                    }
+                    const int ks = optimal_stopping1(pp, cc, p.lam, n_dp, 0, 1.0, 1.0, J);
+                    if (p.k_star) p.k_star[b] = ks;
+                    if (p.stop) p.stop[b] = (ks == p.stage_idx) ? 1 : 0;     // pipeline.py:259
+                }
+            }
+            if (p.theta && p.thr_stop) {
+                const double q = static_cast<double>(sc);                    // minimal_adaptive_decoder.py:159-161
+                p.thr_stop[b] = (q >= p.theta[p.stage_idx] || p.stage_idx == p.L - 1) ? 1 : 0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+inline bool mlp_dims_ok(int in_dim, int hidden) {
+    return in_dim >= 1 && hidden >= 1 && in_dim <= ASD_MAX_MLP_DIM && hidden <= ASD_MAX_MLP_DIM;
+}
+
+}  // namespace
+}  // namespace asd
+
+using namespace asd;
+
+ASD_EXPORT size_t asd_mlp_packed_floats(int in_dim, int hidden) {
+    if (in_dim < 1 || hidden < 1) return 0;
+    return static_cast<size_t>(in_dim) * hidden + 2 * static_cast<size_t>(hidden) + 1;
+}
+
+ASD_EXPORT int asd_mlp_pack_weights(const float* w1, const float* b1, const float* w2, const float* b2, int in_dim,
+                                    int hidden, float* packed) {
+    if (!w1 || !b1 || !w2 || !b2 || !packed) return ASD_ERR_INVALID_ARG;
+    if (!mlp_dims_ok(in_dim, hidden)) return ASD_ERR_UNSUPPORTED;
+    for (int i = 0; i < in_dim; ++i)
+        for (int j = 0; j < hidden; ++j) packed[static_cast<size_t>(i) * hidden + j] = w1[static_cast<size_t>(j) * in_dim + i];
+    float* o = packed + static_cast<size_t>(in_dim) * hidden;
+    for (int j = 0; j < hidden; ++j) o[j] = b1[j];
+    for (int j = 0; j < hidden; ++j) o[hidden + j] = w2[j];
+    o[2 * hidden] = b2[0];
+    return ASD_OK;
+}
+
+ASD_EXPORT int asd_logprob_stats(const float* lp, int64_t ld, const int32_t* n_valid, int B, int K, double* stats,
+                                 void* stream) {
+    if (B < 0 || K < 0) return ASD_ERR_INVALID_ARG;
+    if (B == 0) return ASD_OK;
+    if (!stats || (K > 0 && !lp)) return ASD_ERR_INVALID_ARG;
+    if (K > kStatsMaxK) return ASD_ERR_UNSUPPORTED;
+    if (K > 0 && ld < K) return ASD_ERR_INVALID_ARG;
+    const size_t lds = sizeof(double) * 3 * static_cast<size_t>(K > 0 ? K : 1);
+    hipLaunchKernelGGL(k_logprob_stats, dim3(B), dim3(64), lds, static_cast<hipStream_t>(stream), lp, ld, n_valid, B, K,
+                       stats);
+    return launch_status();
+}
+
+ASD_EXPORT int asd_mlp_predict(const float* x, int64_t ldx, const float* packed_w, int B, int in_dim, int hidden,
+                               float* score, void* stream) {
+    if (B < 0) return ASD_ERR_INVALID_ARG;
+    if (!mlp_dims_ok(in_dim, hidden)) return ASD_ERR_UNSUPPORTED;
+    if (B == 0) return ASD_OK;
+    if (!x || !packed_w || !score || ldx < in_dim) return ASD_ERR_INVALID_ARG;
+    const size_t wbytes = asd_mlp_packed_floats(in_dim, hidden) * sizeof(float);
+    const int use_lds = wbytes <= kWeightLdsLimit;
+    const size_t lds = sizeof(float) * kWavesPerBlock * in_dim + (use_lds ? wbytes : 0);
+    int blocks = (B + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int cap = current_device_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_mlp_predict, dim3(blocks), dim3(64 * kWavesPerBlock), lds, static_cast<hipStream_t>(stream), x,
+                       ldx, packed_w, B, in_dim, hidden, use_lds, score);
+    return launch_status();
+}
+
+ASD_EXPORT int asd_predictor_stop(const float* lp, int64_t ld_lp, const int32_t* n_valid, int K, const float* feat,
+                                  int64_t ldf, int stats_col, const float* packed_w, int in_dim, int hidden,
+                                  int risk_adjustment, int64_t n_obs, double alpha, double beta, double* p_hist,
+                                  const double* C, double lam, int L, int stage_idx, int prefix_rule,
+                                  const double* theta, int B, float* score, int32_t* k_star, uint8_t* stop,
+                                  uint8_t* thr_stop, double* stats, void* stream) {
+    if (B < 0 || K < 0 || L < 1 || stage_idx < 0 || stage_idx >= L) return ASD_ERR_INVALID_ARG;
+    if (L > ASD_MAX_STAGES || K > kFusedMaxK) return ASD_ERR_UNSUPPORTED;
+    if (!mlp_dims_ok(in_dim, hidden)) return ASD_ERR_UNSUPPORTED;
+    if (B == 0) return ASD_OK;
+    if (!feat || !packed_w || ldf < in_dim) return ASD_ERR_INVALID_ARG;
+    if (stats_col >= 0 && stats_col + ASD_NUM_LP_STATS > in_dim) return ASD_ERR_INVALID_ARG;
+    if ((stats_col >= 0 || stats) && (!lp || ld_lp < K)) return ASD_ERR_INVALID_ARG;
+    if ((k_star || stop) && (!p_hist || !C)) return ASD_ERR_INVALID_ARG;
+    FusedParams p{};
+    p.lp = lp; p.ld_lp = ld_lp; p.n_valid = n_valid; p.K = K;
+    p.feat = feat; p.ldf = ldf; p.stats_col = stats_col;
+    p.packed = packed_w; p.in_dim = in_dim; p.hidden = hidden;
+    const size_t wbytes = asd_mlp_packed_floats(in_dim, hidden) * sizeof(float);
+    p.use_lds = wbytes <= kWeightLdsLimit;
+    p.risk = risk_adjustment ? 1 : 0; p.n_obs = static_cast<double>(n_obs); p.alpha = alpha; p.beta = beta;
+    p.p_hist = p_hist; p.C = C; p.lam = lam; p.L = L; p.stage_idx = stage_idx; p.prefix = prefix_rule ? 1 : 0;
+    p.theta = theta; p.B = B;
+    p.score = score; p.k_star = k_star; p.stop = stop; p.thr_stop = thr_stop; p.stats = stats;
+    const size_t lds = sizeof(double) * 3 * static_cast<size_t>(K > 0 ? K : 1) * kWavesPerBlock +
+                       sizeof(float) * kWavesPerBlock * in_dim + (p.use_lds ? wbytes : 0);
+    int blocks = (B + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int cap = current_device_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_predictor_stop, dim3(blocks), dim3(64 * kWavesPerBlock), lds, static_cast<hipStream_t>(stream), p);
+    return launch_status();
+}

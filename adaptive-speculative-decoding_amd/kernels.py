@@ -1,0 +1,282 @@
+"""Device-tensor front end of libasd_hip.so: torch CUDA tensors in, torch CUDA tensors out.
+
+torch is plumbing here (device memory + the current HIP stream); every function below is one
+call through the C ABI with raw device pointers.  Nothing synchronises; outputs are valid in
+stream order.  All of them raise if the tensors are not on a GPU -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _binding as B
+
+_DTYPE_CODE = {torch.float32: B.DTYPE_F32, torch.bfloat16: B.DTYPE_BF16, torch.float16: B.DTYPE_F16}
+
+
+def _lib():
+    return B.load_library()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA (HIP) tensor; this package has no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype=None) -> Optional[int]:
+    return None if t is None else _dev(t, name, dtype)
+
+
+def version() -> int:
+    return _lib().asd_version()
+
+
+def device_cu_count(device: int = 0) -> int:
+    n = _lib().asd_device_cu_count(device)
+    if n < 0:
+        B.check("asd_device_cu_count", n)
+    return n
+
+
+# ------------------------------------------------------------------------------- verify + accept
+class VerifyWorkspace:
+    """Ticket + granule scratch of asd_verify_accept, zeroed once (asd_workspace_init).
+
+    One workspace serves any number of stream-ordered calls with B' <= B, K' <= K; calls that may
+    overlap on different streams need one workspace each."""
+
+    def __init__(self, B_: int, K: int, V: int, dtype: torch.dtype = torch.bfloat16,
+                 device: Optional[torch.device] = None):
+        self.B, self.K, self.V = B_, K, V
+        self.dtype = dtype
+        self.bytes = int(_lib().asd_verify_accept_workspace_bytes(B_, K, V, _DTYPE_CODE[dtype]))
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device or torch.device("cuda"))
+        B.check("asd_workspace_init", _lib().asd_workspace_init(self.buf.data_ptr(), self.bytes, _stream()))
+
+    def fits(self, B_: int, K: int) -> bool:
+        need = int(_lib().asd_verify_accept_workspace_bytes(B_, K, self.V, _DTYPE_CODE[self.dtype]))
+        return need <= self.bytes
+
+
+@dataclass
+class VerifyResult:
+    lp_target: torch.Tensor   # [B,K] f32   log p_target(tok)
+    accept: torch.Tensor      # [B,K] u8
+    n_acc: torch.Tensor       # [B]   i32   accepted-prefix length
+    accept_bits: torch.Tensor  # [B]  i64 (bit k = accept[b,k])
+
+
+def _logits_2d(logits: torch.Tensor, Bv: int, K: int) -> Tuple[int, int, int]:
+    if logits.dtype not in _DTYPE_CODE:
+        raise ValueError(f"logits dtype {logits.dtype} unsupported (f32 / bf16 / f16)")
+    if not logits.is_cuda:
+        raise ValueError("logits must be a CUDA (HIP) tensor; this package has no CPU path")
+    if logits.dim() == 3:
+        if logits.shape[0] != Bv or logits.shape[1] != K:
+            raise ValueError("logits must be [B,K,V]")
+        if logits.stride(2) != 1 or logits.stride(0) != K * logits.stride(1):
+            raise ValueError("logits rows must be unit-stride in V and evenly spaced over (b,k)")
+        return logits.shape[2], logits.stride(1), logits.data_ptr()
+    if logits.dim() == 2:
+        if logits.shape[0] != Bv * K or logits.stride(1) != 1:
+            raise ValueError("2-D logits must be [B*K, V] with unit stride in V")
+        return logits.shape[1], logits.stride(0), logits.data_ptr()
+    raise ValueError("logits must be [B,K,V] or [B*K,V]")
+
+
+def verify_accept(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
+                  workspace: VerifyWorkspace, out: Optional[VerifyResult] = None, *, splits: int = 0,
+                  threads: int = 0, unroll: int = 0, nontemporal: int = -1) -> VerifyResult:
+    """A5/A6 in one launch (include/asd_hip.h: asd_verify_accept).  tok/lp_draft/u: [B,K]."""
+    Bv, K = tok.shape
+    V, ld, ptr = _logits_2d(logits, Bv, K)
+    dev = logits.device
+    if out is None:
+        out = VerifyResult(torch.empty((Bv, K), dtype=torch.float32, device=dev),
+                           torch.empty((Bv, K), dtype=torch.uint8, device=dev),
+                           torch.empty((Bv,), dtype=torch.int32, device=dev),
+                           torch.empty((Bv,), dtype=torch.int64, device=dev))
+    rc = _lib().asd_verify_accept_tuned(
+        ptr, _DTYPE_CODE[logits.dtype], ld, _dev(tok, "tok", torch.int32), _dev(lp_draft, "lp_draft", torch.float32),
+        _dev(u, "u", torch.float32), Bv, K, V, _dev(out.lp_target, "lp_target", torch.float32),
+        _dev(out.accept, "accept", torch.uint8), _dev(out.n_acc, "n_acc", torch.int32),
+        _dev(out.accept_bits, "accept_bits", torch.int64), workspace.buf.data_ptr(), workspace.bytes, _stream(),
+        splits, threads, unroll, nontemporal)
+    B.check("asd_verify_accept", rc)
+    return out
+
+
+def lse_partial(logits_shard: torch.Tensor, tok: torch.Tensor, v_offset: int, workspace: VerifyWorkspace,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-shard (m2, s, g) triples, [B,K,3] f32, with sum_v exp(x) = s * 2^m2 (log2 domain)."""
+    Bv, K = tok.shape
+    V, ld, ptr = _logits_2d(logits_shard, Bv, K)
+    if out is None:
+        out = torch.empty((Bv, K, 3), dtype=torch.float32, device=logits_shard.device)
+    rc = _lib().asd_lse_partial(ptr, _DTYPE_CODE[logits_shard.dtype], ld, _dev(tok, "tok", torch.int32), Bv, K, V,
+                                int(v_offset), _dev(out, "msg", torch.float32), workspace.buf.data_ptr(),
+                                workspace.bytes, _stream())
+    B.check("asd_lse_partial", rc)
+    return out
+
+
+def accept_from_partials(msg_all: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
+                         out: Optional[VerifyResult] = None) -> VerifyResult:
+    """msg_all: [n_shards,B,K,3] (all-gathered asd_lse_partial outputs, shard order fixed)."""
+    n_shards, Bv, K, three = msg_all.shape
+    assert three == 3
+    dev = msg_all.device
+    if out is None:
+        out = VerifyResult(torch.empty((Bv, K), dtype=torch.float32, device=dev),
+                           torch.empty((Bv, K), dtype=torch.uint8, device=dev),
+                           torch.empty((Bv,), dtype=torch.int32, device=dev),
+                           torch.empty((Bv,), dtype=torch.int64, device=dev))
+    rc = _lib().asd_accept_from_partials(_dev(msg_all, "msg_all", torch.float32), n_shards,
+                                         _dev(lp_draft, "lp_draft", torch.float32), _dev(u, "u", torch.float32), Bv, K,
+                                         out.lp_target.data_ptr(), out.accept.data_ptr(), out.n_acc.data_ptr(),
+                                         out.accept_bits.data_ptr(), _stream())
+    B.check("asd_accept_from_partials", rc)
+    return out
+
+
+# ------------------------------------------------------------------------------- predictor side
+def logprob_stats(lp: torch.Tensor, n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A7: [B,K] f32 log-probs -> [B,5] f64 (mean, std, min, q25, median), numpy semantics."""
+    Bv, K = lp.shape
+    out = torch.empty((Bv, 5), dtype=torch.float64, device=lp.device)
+    rc = _lib().asd_logprob_stats(_dev(lp, "lp", torch.float32), lp.stride(0) if Bv else K,
+                                  _opt(n_valid, "n_valid", torch.int32), Bv, K, out.data_ptr(), _stream())
+    B.check("asd_logprob_stats", rc)
+    return out
+
+
+def pack_mlp_weights(w1, b1, w2, b2, device=None) -> torch.Tensor:
+    """state_dict tensors (net.0.weight [H,D], net.0.bias [H], net.3.weight [1,H], net.3.bias [1])
+    -> packed device buffer of asd_mlp_predict."""
+    w1 = np.ascontiguousarray(torch.as_tensor(w1).detach().cpu().numpy(), dtype=np.float32)
+    H, D = w1.shape
+    b1 = np.ascontiguousarray(torch.as_tensor(b1).detach().cpu().numpy(), dtype=np.float32).reshape(H)
+    w2 = np.ascontiguousarray(torch.as_tensor(w2).detach().cpu().numpy(), dtype=np.float32).reshape(H)
+    b2 = np.ascontiguousarray(torch.as_tensor(b2).detach().cpu().numpy(), dtype=np.float32).reshape(1)
+    n = int(_lib().asd_mlp_packed_floats(D, H))
+    packed = np.empty(n, np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    B.check("asd_mlp_pack_weights", _lib().asd_mlp_pack_weights(vp(w1), vp(b1), vp(w2), vp(b2), D, H, vp(packed)))
+    t = torch.from_numpy(packed)
+    return t.to(device or torch.device("cuda"))
+
+
+def mlp_predict(x: torch.Tensor, packed_w: torch.Tensor, in_dim: int, hidden: int) -> torch.Tensor:
+    """A8 (eval mode): x [B,in_dim] f32 -> score [B] f32."""
+    Bv = x.shape[0]
+    out = torch.empty((Bv,), dtype=torch.float32, device=x.device)
+    rc = _lib().asd_mlp_predict(_dev(x, "x", torch.float32), x.stride(0) if Bv else in_dim,
+                                _dev(packed_w, "packed_w", torch.float32), Bv, in_dim, hidden, out.data_ptr(), _stream())
+    B.check("asd_mlp_predict", rc)
+    return out
+
+
+def threshold_stop(score: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
+    """A11: first stage s with score >= theta[s] (or the last)."""
+    out = torch.empty((score.shape[0],), dtype=torch.int32, device=score.device)
+    rc = _lib().asd_threshold_stop(_dev(score, "score", torch.float32), _dev(theta, "theta", torch.float64),
+                                   score.shape[0], theta.shape[0], out.data_ptr(), _stream())
+    B.check("asd_threshold_stop", rc)
+    return out
+
+
+def bayes_adjust(p: torch.Tensor, n_obs: int, alpha: float = 1.0, beta: float = 1.0) -> torch.Tensor:
+    """A2 over a flat f64 tensor."""
+    out = torch.empty_like(p)
+    rc = _lib().asd_bayes_adjust(_dev(p, "p", torch.float64), int(n_obs), float(alpha), float(beta), p.numel(),
+                                 out.data_ptr(), _stream())
+    B.check("asd_bayes_adjust", rc)
+    return out
+
+
+def optimal_stopping(p: torch.Tensor, Cc: torch.Tensor, lam: float, risk_adjustment: bool = False,
+                     alpha: float = 1.0, beta: float = 1.0, want_J: bool = True):
+    """A1 batched: p [B,L] f64, C [L] f64 -> (k_star [B] i32, J [B,L+1] f64 or None)."""
+    Bv, L = p.shape
+    if Cc.numel() != L:
+        raise ValueError("p and C must have the same length")  # dp_solver.py:34-35
+    k = torch.empty((Bv,), dtype=torch.int32, device=p.device)
+    J = torch.empty((Bv, L + 1), dtype=torch.float64, device=p.device) if want_J else None
+    rc = _lib().asd_optimal_stopping(_dev(p, "p", torch.float64), _dev(Cc, "C", torch.float64), float(lam), Bv, L,
+                                     int(bool(risk_adjustment)), float(alpha), float(beta), k.data_ptr(),
+                                     None if J is None else J.data_ptr(), _stream())
+    B.check("asd_optimal_stopping", rc)
+    return k, J
+
+
+def expected_cost(p: torch.Tensor, Cc: torch.Tensor, lam: float, k: torch.Tensor) -> torch.Tensor:
+    """A3 batched."""
+    Bv, L = p.shape
+    out = torch.empty((Bv,), dtype=torch.float64, device=p.device)
+    rc = _lib().asd_expected_cost(_dev(p, "p", torch.float64), _dev(Cc, "C", torch.float64), float(lam),
+                                  _dev(k, "k", torch.int32), Bv, L, out.data_ptr(), _stream())
+    B.check("asd_expected_cost", rc)
+    return out
+
+
+def derive_thresholds(q, c, lam: float) -> Tuple[np.ndarray, np.ndarray]:
+    """A10 (host entry point of the library; O(n) f64, once per set_lambda)."""
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1)
+    c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
+    if q.size != c.size:
+        raise ValueError("quality_bounds and cost_ratios must have the same length")
+    theta = np.empty(q.size, np.float64)
+    V = np.empty(q.size + 1, np.float64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    B.check("asd_derive_thresholds", _lib().asd_derive_thresholds(vp(q), vp(c), q.size, float(lam), vp(theta), vp(V)))
+    return theta, V
+
+
+@dataclass
+class StopResult:
+    score: torch.Tensor       # [B] f32   predictor output
+    k_star: Optional[torch.Tensor]    # [B] i32   DP rule
+    stop: Optional[torch.Tensor]      # [B] u8    k_star == stage_idx
+    thr_stop: Optional[torch.Tensor]  # [B] u8    score >= theta[stage_idx] (or last stage)
+    stats: Optional[torch.Tensor]     # [B,5] f64
+
+
+def predictor_stop(feat: torch.Tensor, packed_w: torch.Tensor, in_dim: int, hidden: int, *, stage_idx: int, L: int,
+                   lp: Optional[torch.Tensor] = None, n_valid: Optional[torch.Tensor] = None, stats_col: int = -1,
+                   risk_adjustment: bool = True, n_obs: int = 100, alpha: float = 1.0, beta: float = 1.0,
+                   p_hist: Optional[torch.Tensor] = None, Cc: Optional[torch.Tensor] = None, lam: float = 1.0,
+                   prefix_rule: bool = False, theta: Optional[torch.Tensor] = None,
+                   want_stats: bool = False) -> StopResult:
+    """Fused post-verify epilogue (asd_predictor_stop): stats -> features -> MLP -> Bayes -> DP / theta."""
+    Bv = feat.shape[0]
+    dev = feat.device
+    score = torch.empty((Bv,), dtype=torch.float32, device=dev)
+    dp = p_hist is not None and Cc is not None
+    k_star = torch.empty((Bv,), dtype=torch.int32, device=dev) if dp else None
+    stop = torch.empty((Bv,), dtype=torch.uint8, device=dev) if dp else None
+    thr = torch.empty((Bv,), dtype=torch.uint8, device=dev) if theta is not None else None
+    stats = torch.empty((Bv, 5), dtype=torch.float64, device=dev) if want_stats else None
+    K = 0 if lp is None else lp.shape[1]
+    rc = _lib().asd_predictor_stop(
+        _opt(lp, "lp", torch.float32), (lp.stride(0) if lp is not None and Bv else K), _opt(n_valid, "n_valid", torch.int32),
+        K, _dev(feat, "feat", torch.float32), feat.stride(0) if Bv else in_dim, stats_col,
+        _dev(packed_w, "packed_w", torch.float32), in_dim, hidden, int(bool(risk_adjustment)), int(n_obs), float(alpha),
+        float(beta), _opt(p_hist, "p_hist", torch.float64), _opt(Cc, "C", torch.float64), float(lam), L, stage_idx,
+        int(bool(prefix_rule)), _opt(theta, "theta", torch.float64), Bv, score.data_ptr(),
+        None if k_star is None else k_star.data_ptr(), None if stop is None else stop.data_ptr(),
+        None if thr is None else thr.data_ptr(), None if stats is None else stats.data_ptr(), _stream())
+    B.check("asd_predictor_stop", rc)
+    return StopResult(score, k_star, stop, thr, stats)

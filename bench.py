@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Benchmark of the draft-verify / accept / stop hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5]
+
+A step = ONE pass of the hot path over one batch of synthetic target logits already resident in
+HBM:  asd_verify_accept (gather + log-sum-exp + acceptance test over [B,K,V] bf16)  followed by
+asd_predictor_stop (log-prob statistics -> 64-d features -> 64x32x1 predictor -> Bayes -> DP stop
+rule).  Logits buffers rotate through > 600 MB so the figure is HBM, not Infinity Cache.
+Prints ONE JSON line (rank 0).  `value` = verified tokens / s = sum_b (n_acc[b] + 1) per second,
+whole job.  N > 1: one process per GPU, every rank verifies its own batch of the same shape
+(batch-parallel replicas, no data-path collective; "weak" scaling).
+
+roofline: the verify kernel's ALGORITHMIC bytes (B*K*V*2 + 17*B*K + 4*B, +8*B for
+the ballot word) divided by its mean duration, measured with HIP events recorded on the launch
+stream around every verify launch of the timed region.  cpu_baseline: the C oracle (oracle/,
+OpenMP over rows) on the host cores, same workload, bounded sample, rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (B, K, V, description)
+    "c2": (8, 8, 152064, "BASELINE configs[1]: batch 8, draft_len 8, vocab 152064 (Qwen2.5), bf16 logits"),
+    "c3": (32, 8, 152064, "BASELINE headline: batch 32, draft_len 8, vocab 152064 (Qwen2.5), bf16 logits"),
+    "c5": (128, 8, 152064, "BASELINE configs[4] per-node batch: batch 128, draft_len 8, vocab 152064, bf16 logits"),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_STAGES = 3                 # 7B / 32B / 72B tiers
+STAGE_COSTS = [1.0, 4.5, 10.0]
+
+
+def algorithmic_bytes(B, K, V, esz=2):
+    return B * K * V * esz + B * K * (4 + 4 + 4) + B * K * (4 + 1) + B * 4 + B * 8
+
+
+def build_inputs(torch, Kmod, B, K, V, nbuf, device, seed):
+    """Synthetic inputs per BASELINE.md §3: logits ~ 4*N(0,1) (bf16); tok = target arg-max w.p. 0.7 else
+    uniform; lp_d = lp_t + N(0, 0.5) clipped <= 0; u ~ U(0,1)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ws = Kmod.VerifyWorkspace(B, K, V, torch.bfloat16, device)
+    bufs = []
+    for _ in range(nbuf):
+        lg = torch.empty((B, K, V), dtype=torch.bfloat16, device=device)
+        for b in range(B):   # row-block generation keeps the f32 temporary small
+            lg[b] = (torch.randn((K, V), generator=g, device=device) * 4.0).to(torch.bfloat16)
+        amax = lg.argmax(dim=-1).to(torch.int32)
+        rnd = torch.randint(0, V, (B, K), generator=g, device=device, dtype=torch.int32)
+        pick = torch.rand((B, K), generator=g, device=device) < 0.7
+        tok = torch.where(pick, amax, rnd).contiguous()
+        zero = torch.zeros((B, K), device=device)
+        half = torch.full((B, K), 0.5, device=device)
+        lp_t = Kmod.verify_accept(lg, tok, zero, half, ws).lp_target
+        lp_d = torch.clamp(lp_t + torch.randn((B, K), generator=g, device=device) * 0.5, max=0.0).contiguous()
+        u = torch.rand((B, K), generator=g, device=device).contiguous()
+        out = Kmod.VerifyResult(torch.empty((B, K), dtype=torch.float32, device=device),
+                                torch.empty((B, K), dtype=torch.uint8, device=device),
+                                torch.empty((B,), dtype=torch.int32, device=device),
+                                torch.empty((B,), dtype=torch.int64, device=device))
+        bufs.append(dict(logits=lg, tok=tok, lp_d=lp_d, u=u, out=out))
+    return ws, bufs
+
+
+def predictor_weights(np):
+    rng = np.random.default_rng(20251004)
+    w1 = (rng.standard_normal((32, 64)) / 8.0).astype(np.float32)
+    b1 = (rng.standard_normal(32) * 0.05).astype(np.float32)
+    w2 = (rng.standard_normal((1, 32)) / 5.0).astype(np.float32)
+    b2 = np.zeros(1, np.float32)
+    return w1, b1, w2, b2
+
+
+def cpu_baseline(np, torch, buf, B, K, V, weights, feat, budget_s=12.0):
+    """The oracle (oracle/asd_oracle.c, f64 accumulation, OpenMP over rows) on the host cores."""
+    from oracle import oracle as O
+
+    O.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    store = buf["logits"].view(torch.int16).cpu().numpy().view(np.uint16).reshape(B * K, V)
+    tok = buf["tok"].cpu().numpy()
+    lp_d = buf["lp_d"].cpu().numpy()
+    u = buf["u"].cpu().numpy()
+    w1, b1, w2, b2 = weights
+    Cc = np.asarray(STAGE_COSTS)
+
+    def one_pass():
+        r = O.verify_accept(store, O.DT_BF16, tok, lp_d, u, B, K, V, n_threads=cores)
+        stats = O.logprob_stats(r["lp_t"], None, K)      # all K target log-probs, as the GPU step does
+        x = feat.copy()
+        x[:, 5:10] = stats.astype(np.float32)
+        score = O.mlp_predict(x, w1, b1, w2[0], b2)
+        hist = np.ones((B, N_STAGES))
+        hist[:, 0] = O.bayes_adjust(score.astype(np.float64), 100)
+        O.optimal_stopping(hist, Cc, 1.0)
+        return int(r["n_acc"].sum()) + B
+
+    t0 = time.perf_counter()
+    tokens = one_pass()
+    first = time.perf_counter() - t0
+    passes = max(1, min(200, int(budget_s / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    total = 0
+    for _ in range(passes):
+        total += one_pass()
+    dt = time.perf_counter() - t0
+    # the reference's own idiom (generate_training_data.py:128-134): per-token torch loop, small sample
+    import torch.nn.functional as F
+    rows = min(16, B * K)
+    xs = buf["logits"].reshape(B * K, V)[:rows].float().cpu()
+    tk = buf["tok"].reshape(-1)[:rows].cpu()
+    torch.set_num_threads(cores)
+    t1 = time.perf_counter()
+    for i in range(rows):
+        probs = F.softmax(xs[i], dim=-1)
+        torch.log(probs[tk[i]]).item()
+    idiom_row_s = (time.perf_counter() - t1) / rows
+    return dict(value=total / dt, unit="tokens/s", cores=cores, kind="port",
+                sample=f"{passes} full passes of the same B={B} K={K} V={V} bf16 step through oracle/asd_oracle.c "
+                       f"(f64 LSE, OpenMP over rows, {cores} threads) in {dt:.1f} s",
+                ms_per_step=1e3 * dt / passes, tokens_per_step=tokens,
+                reference_idiom_ms_per_row=1e3 * idiom_row_s,
+                reference_idiom_note="generate_training_data.py:128-134 per-token softmax->index->log->.item() "
+                                     f"with torch CPU f32, {rows}-row sample")
+
+
+def load_traffic():
+    """HBM bytes per verify launch from the last committed PMC pass (profiles/*traffic.json), or None."""
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        cands = sorted(f for f in os.listdir(pdir) if f.endswith("traffic.json"))
+    except OSError:
+        return None, None
+    if not cands:
+        return None, None
+    try:
+        with open(os.path.join(pdir, cands[-1])) as f:
+            d = json.load(f)
+        return d, "profiles/" + cands[-1]
+    except Exception:
+        return None, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--splits", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--unroll", type=int, default=0)
+    ap.add_argument("--nontemporal", type=int, default=-1)
+    ap.add_argument("--verify-only", action="store_true", help="skip the predictor/stop epilogue launch")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from asd_amd import kernels as Kmod
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    B, K, V, desc = WORKLOADS[args.workload]
+    bytes_per_launch = algorithmic_bytes(B, K, V)
+    nbuf = max(3, math.ceil(640e6 / (B * K * V * 2)))
+    ws, bufs = build_inputs(torch, Kmod, B, K, V, nbuf, device, seed=1234 + rank)
+    weights = predictor_weights(np)
+    packed = Kmod.pack_mlp_weights(*weights, device=device)
+    feat_np = (np.random.default_rng(7).standard_normal((B, 64)) * 0.3).astype(np.float32)
+    feat = torch.from_numpy(feat_np).to(device)
+    Cc = torch.tensor(STAGE_COSTS, dtype=torch.float64, device=device)
+    p_hist = torch.ones((B, N_STAGES), dtype=torch.float64, device=device)
+    lib = Kmod._lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    geom = (args.splits, args.threads, args.unroll, args.nontemporal)
+
+    # pre-bound launch closures: no allocation, no Python-side tensor work inside the timed loop
+    score = torch.empty((B,), dtype=torch.float32, device=device)
+    k_star = torch.empty((B,), dtype=torch.int32, device=device)
+    stop = torch.empty((B,), dtype=torch.uint8, device=device)
+    n_valid = torch.full((B,), K, dtype=torch.int32, device=device)
+
+    def verify(buf):
+        o = buf["out"]
+        rc = lib.asd_verify_accept_tuned(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(),
+                                         buf["u"].data_ptr(), B, K, V, o.lp_target.data_ptr(), o.accept.data_ptr(),
+                                         o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes,
+                                         stream, *geom)
+        if rc:
+            raise RuntimeError(f"asd_verify_accept_tuned rc={rc}")
+
+    def epilogue(buf):
+        o = buf["out"]
+        rc = lib.asd_predictor_stop(o.lp_target.data_ptr(), K, n_valid.data_ptr(), K, feat.data_ptr(), 64, 5,
+                                    packed.data_ptr(), 64, 32, 1, 100, 1.0, 1.0, p_hist.data_ptr(), Cc.data_ptr(), 1.0,
+                                    N_STAGES, 0, 0, None, B, score.data_ptr(), k_star.data_ptr(), stop.data_ptr(),
+                                    None, None, stream)
+        if rc:
+            raise RuntimeError(f"asd_predictor_stop rc={rc}")
+
+    def step(i, ev=None):
+        buf = bufs[i % nbuf]
+        if ev is not None:
+            ev[0].record()
+        verify(buf)
+        if ev is not None:
+            ev[1].record()
+        if not args.verify_only:
+            epilogue(buf)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, events[i])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # verified tokens: outputs per buffer are deterministic, so count them after the timed region
+    per_buf = [int(b["out"].n_acc.sum().item()) + B for b in bufs]
+    tokens = sum(per_buf[(args.warmup + i) % nbuf] for i in range(args.steps))
+    kern_ms = [a.elapsed_time(b) for a, b in events]
+    kern_ms.sort()
+    kern_mean_ms = sum(kern_ms) / len(kern_ms)
+    kern_med_ms = kern_ms[len(kern_ms) // 2]
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tk = torch.tensor([tokens], dtype=torch.float64, device=device)
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        tokens = int(tk.item())
+        km = torch.tensor([kern_mean_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kern_mean_ms = float(km.item())
+
+    if rank == 0:
+        achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
+        traffic, traffic_src = load_traffic()
+        out = {
+            "metric": "verified_tokens_per_s",
+            "value": tokens / elapsed,
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}; step = asd_verify_accept"
+                                   + ("" if args.verify_only else " + asd_predictor_stop (stats->MLP->Bayes->DP)"),
+                       "batch_per_gpu": B, "draft_len": K, "vocab": V, "accumulate": "f32 (epilogue f64)",
+                       "rotating_buffers": nbuf, "buffer_MB": round(B * K * V * 2 / 1e6, 2),
+                       "tiers": "7B-draft / 32B / 72B-target shapes (vocab 152064); logits synthetic",
+                       "parallelism": f"batch-parallel replicas x{world}" if world > 1 else "single GPU",
+                       "geometry": {"splits": args.splits, "threads": args.threads, "unroll": args.unroll,
+                                    "nontemporal": args.nontemporal}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
+                         "traffic_source": traffic_src,
+                         "kernel": "asd::k_verify (verify_accept.hip)", "algorithmic_bytes": bytes_per_launch,
+                         "kernel_ms_mean": kern_mean_ms, "kernel_ms_median": kern_med_ms,
+                         "kernel_ms_p10": kern_ms[len(kern_ms) // 10], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10],
+                         "timing": "HIP events on the launch stream around every verify launch of the timed region"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(np, torch, bufs[0], B, K, V, weights, feat_np, args.cpu_budget_s)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

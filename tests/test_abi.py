@@ -1,0 +1,77 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every symbol include/asd_hip.h
+declares; the ctypes prototypes cover exactly that set.  No compute call is made here except
+the host-only entry points (asd_version, asd_status_string, asd_mlp_pack*, asd_derive_thresholds)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "asd_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(asd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from asd_amd import _binding
+    lib = _binding.load_library()
+    names = _declared()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"{n} not exported by libasd_hip.so"
+    assert sorted(_binding.SIGNATURES) == names
+
+
+def test_version_and_status_strings():
+    from asd_amd import _binding
+    lib = _binding.load_library()
+    assert lib.asd_version() == 100
+    assert lib.asd_status_string(0) == b"ok"
+    assert b"workspace" in lib.asd_status_string(-3)
+    assert lib.asd_verify_accept_workspace_bytes(32, 8, 152064, 1) % 256 == 0
+    assert lib.asd_mlp_packed_floats(64, 32) == 2113
+
+
+def test_host_entry_points_match_goldens(golden):
+    """asd_derive_thresholds and asd_mlp_pack_weights run on the host: bit-exact vs the goldens."""
+    from asd_amd import kernels as K
+    for row in golden.json("thresholds.json")["rows"]:
+        theta, _ = K.derive_thresholds(row["q"], row["c"], row["lam"])
+        assert theta.tolist() == row["theta"]
+    from asd_amd import _binding
+    lib = _binding.load_library()
+    g = golden.npz("predictor.npz")
+    packed = np.empty(2113, np.float32)
+    vp = lambda a: np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.c_void_p)
+    w1, b1, w2, b2 = (np.ascontiguousarray(g[k], dtype=np.float32) for k in ("w1", "b1", "w2", "b2"))
+    assert lib.asd_mlp_pack_weights(w1.ctypes.data_as(C.c_void_p), b1.ctypes.data_as(C.c_void_p),
+                                    w2.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p), 64, 32,
+                                    packed.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(packed[:64 * 32].reshape(64, 32), w1.T)
+    assert np.array_equal(packed[2048:2080], b1) and np.array_equal(packed[2080:2112], w2[0]) and packed[2112] == b2[0]
+
+
+def test_product_fails_loudly_without_gpu():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from asd_amd import backend
+    backend.set_backend(None)
+    from asd_amd.algorithms import optimal_stopping_rule
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        optimal_stopping_rule([0.5], [1.0], 1.0)
+
+
+def test_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "adaptive-speculative-decoding_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "libasd_oracle" not in text, f

@@ -1,0 +1,126 @@
+"""Predictor-side kernels (A7 stats, A8 MLP, fused epilogue) against goldens and the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCORE_ATOL = 1e-5      # BASELINE.json: stopping scores within 1e-5 fp32 (observed ~1e-7)
+
+
+@pytest.fixture(scope="module")
+def K_():
+    from asd_amd import kernels
+    return kernels
+
+
+def _cuda(a, dtype):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+def test_mlp_golden_scores(golden, K_):
+    g = golden.npz("predictor.npz")
+    packed = K_.pack_mlp_weights(g["w1"], g["b1"], g["w2"], g["b2"])
+    got = K_.mlp_predict(_cuda(g["X"], np.float32), packed, 64, 32).cpu().numpy()
+    np.testing.assert_allclose(got, g["scores"], rtol=0, atol=SCORE_ATOL)
+    np.testing.assert_allclose(got, g["scores_one_by_one"], rtol=0, atol=SCORE_ATOL)
+    print("max |score_gpu - score_torch| =", np.abs(got - g["scores"]).max())
+
+
+@pytest.mark.parametrize("D,H,B", [(64, 32, 1), (64, 32, 100003), (256, 128, 777), (5, 3, 9), (1024, 1024, 5),
+                                   (100, 65, 130)])
+def test_mlp_shapes_vs_oracle(K_, D, H, B):
+    rng = np.random.default_rng(D * 1000 + H)
+    w1 = (rng.standard_normal((H, D)) / np.sqrt(D)).astype(np.float32)
+    b1 = rng.standard_normal(H).astype(np.float32) * 0.1
+    w2 = (rng.standard_normal(H) / np.sqrt(H)).astype(np.float32)
+    b2 = rng.standard_normal(1).astype(np.float32)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    packed = K_.pack_mlp_weights(w1, b1, w2[None, :], b2)
+    got = K_.mlp_predict(_cuda(x, np.float32), packed, D, H).cpu().numpy()
+    want = O.mlp_predict(x, w1, b1, w2, b2)
+    np.testing.assert_allclose(got, want, rtol=0, atol=SCORE_ATOL)
+
+
+def test_logprob_stats_goldens_bit_exact(golden, K_):
+    """A7 columns [5:10] of the reference's extract_features, float64, bit for bit."""
+    g = golden.npz("features_a7.npz")
+    lp = g["logprobs"].astype(np.float32)
+    got = K_.logprob_stats(_cuda(lp, np.float32), _cuda(g["n_valid"], np.int32)).cpu().numpy()
+    want = np.ascontiguousarray(g["features"][:, 5:10])
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("K", [1, 2, 7, 8, 9, 64, 129, 300, 1024])
+def test_logprob_stats_vs_numpy(K_, K):
+    rng = np.random.default_rng(K)
+    B = 37
+    lp = (-np.abs(rng.standard_normal((B, K))) * 3).astype(np.float32)
+    lp[0, : min(K, 3)] = lp[0, 0]                      # ties
+    nv = rng.integers(0, K + 1, B).astype(np.int32)
+    nv[1] = K
+    nv[2] = 0
+    got = K_.logprob_stats(_cuda(lp, np.float32), _cuda(nv, np.int32)).cpu().numpy()
+    for b in range(B):
+        want = O.py_logprob_stats([float(v) for v in lp[b, :nv[b]]])
+        assert got[b].tolist() == want, (b, nv[b])
+    full = K_.logprob_stats(_cuda(lp, np.float32)).cpu().numpy()
+    assert full[5].tolist() == O.py_logprob_stats([float(v) for v in lp[5]])
+
+
+def test_fused_epilogue_equals_composition(golden, K_):
+    """asd_predictor_stop == stats -> feature overlay -> MLP -> Bayes -> DP rule / theta test."""
+    import torch
+    g = golden.npz("predictor.npz")
+    rng = np.random.default_rng(8)
+    B, K, L = 200, 8, 3
+    packed = K_.pack_mlp_weights(g["w1"], g["b1"], g["w2"], g["b2"])
+    feat = rng.standard_normal((B, 64)).astype(np.float32) * 0.3
+    lp = (-np.abs(rng.standard_normal((B, K))) * 2).astype(np.float32)
+    nv = rng.integers(0, K + 1, B).astype(np.int32)
+    Cc = np.array([1.0, 4.5, 10.0])
+    theta, _ = O.derive_thresholds([0.7, 0.85, 0.9], Cc, 0.1)
+    for stage_idx in (0, 1, 2):
+        for prefix in (False, True):
+            for risk in (False, True):
+                p_hist = rng.uniform(0.2, 1.0, (B, L))
+                p_hist[:, L - 1] = 1.0
+                ph = _cuda(p_hist, np.float64)
+                r = K_.predictor_stop(_cuda(feat, np.float32), packed, 64, 32, stage_idx=stage_idx, L=L,
+                                      lp=_cuda(lp, np.float32), n_valid=_cuda(nv, np.int32), stats_col=5,
+                                      risk_adjustment=risk, n_obs=150, alpha=1.0, beta=2.0, p_hist=ph,
+                                      Cc=_cuda(Cc, np.float64), lam=0.7, prefix_rule=prefix,
+                                      theta=_cuda(theta, np.float64), want_stats=True)
+                torch.cuda.synchronize()
+                stats = O.logprob_stats(lp, nv, K)
+                assert r.stats.cpu().numpy().tobytes() == stats.tobytes()
+                x = feat.copy()
+                x[:, 5:10] = stats.astype(np.float32)
+                score = O.mlp_predict(x, g["w1"], g["b1"], g["w2"][0], g["b2"])
+                got_score = r.score.cpu().numpy()
+                np.testing.assert_allclose(got_score, score, rtol=0, atol=SCORE_ATOL)
+                # decisions are checked on the GPU's own score (bit-exact chain from there on)
+                prob = got_score.astype(np.float64)
+                if risk:
+                    prob = O.bayes_adjust(prob, 150, 1.0, 2.0)
+                want_hist = p_hist.copy()
+                want_hist[:, stage_idx] = prob
+                assert ph.cpu().numpy().tobytes() == want_hist.tobytes()
+                n_dp = stage_idx + 1 if prefix else L
+                ks, _ = O.optimal_stopping(want_hist[:, :n_dp], Cc[:n_dp], 0.7)
+                assert np.array_equal(r.k_star.cpu().numpy(), ks)
+                assert np.array_equal(r.stop.cpu().numpy(), (ks == stage_idx).astype(np.uint8))
+                thr = ((got_score.astype(np.float64) >= theta[stage_idx]) | (stage_idx == L - 1)).astype(np.uint8)
+                assert np.array_equal(r.thr_stop.cpu().numpy(), thr)
+                if prefix and stage_idx == 0:
+                    assert bool((r.stop == 1).all())       # the prefix rule always stops at stage 0
+
+
+def test_fused_epilogue_without_stats(golden, K_):
+    g = golden.npz("predictor.npz")
+    packed = K_.pack_mlp_weights(g["w1"], g["b1"], g["w2"], g["b2"])
+    r = K_.predictor_stop(_cuda(g["X"], np.float32), packed, 64, 32, stage_idx=0, L=4, risk_adjustment=False)
+    np.testing.assert_allclose(r.score.cpu().numpy(), g["scores"], rtol=0, atol=SCORE_ATOL)
+    assert r.k_star is None and r.thr_stop is None

@@ -1,0 +1,239 @@
+"""Parity of the HIP verify+accept path (through the C ABI) against the CPU oracle.
+
+Bars (BASELINE.json): accept mask / n_acc / ballot word bit-exact on the margin-filtered set,
+log-probs within atol 1e-5 + rtol 1e-6.  The accept test itself has no reference symbol
+(SURVEY.md F2): parity unpinned for A5, the log-prob half is pinned to A6 via the golden
+logprob_idiom.npz.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import (LP_ATOL, assert_verify_matches, make_verify_case, run_gpu_verify, to_device_logits)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K_():
+    from asd_amd import kernels
+    return kernels
+
+
+@pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32, O.DT_F16])
+def test_c1_plumbing_case(dtype):
+    """BASELINE configs[0] shape: batch 1, draft_len 4, vocab 1k."""
+    case = make_verify_case(1, 4, 1000, dtype, seed=1)
+    assert_verify_matches(run_gpu_verify(case), case["ref"])
+
+
+@pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32, O.DT_F16])
+@pytest.mark.parametrize("V,ld", [(1001, 1001), (1000, 1003), (7, 7), (1, 5), (4099, 4101), (33, 40)])
+def test_ragged_and_misaligned_rows(dtype, V, ld):
+    """Odd vocab sizes and row strides: rows start off 16-byte alignment, head/tail scalars run."""
+    case = make_verify_case(3, 5, V, dtype, seed=V + ld, ld_row=ld)
+    assert_verify_matches(run_gpu_verify(case), case["ref"])
+
+
+@pytest.mark.parametrize("B", [8, 32])
+def test_full_size_bf16(B):
+    """BASELINE configs[1] (B=8) and the headline config (B=32), draft_len 8, vocab 152064."""
+    case = make_verify_case(B, 8, 152064, O.DT_BF16, seed=1234, n_threads=16)
+    got = run_gpu_verify(case)
+    assert_verify_matches(got, case["ref"])
+    err = np.abs(got["lp_t"].astype(np.float64) - case["ref"]["lp_t64"]).max()
+    print(f"B={B}: max |lp_gpu - lp_oracle| = {err:.3e}")
+    assert err < LP_ATOL
+
+
+def test_full_size_f32_and_f16():
+    for dtype in (O.DT_F32, O.DT_F16):
+        case = make_verify_case(4, 8, 152064, dtype, seed=99, n_threads=16)
+        assert_verify_matches(run_gpu_verify(case), case["ref"])
+
+
+@pytest.mark.parametrize("threads", [256, 512, 1024])
+@pytest.mark.parametrize("unroll", [2, 4, 8])
+def test_every_geometry_agrees(threads, unroll):
+    """All launch geometries of asd_verify_accept_tuned give the oracle's answer."""
+    case = make_verify_case(4, 8, 50000, O.DT_BF16, seed=5)
+    for splits in (1, 2, 3, 7, 16):
+        for nt in (0, 1):
+            got = run_gpu_verify(case, splits=splits, threads=threads, unroll=unroll, nontemporal=nt)
+            assert_verify_matches(got, case["ref"])
+
+
+def test_geometry_limits_are_reported(K_):
+    import torch
+    case = make_verify_case(2, 64, 640, O.DT_BF16, seed=3)
+    assert_verify_matches(run_gpu_verify(case), case["ref"])           # K = 64 = ASD_MAX_DRAFT_LEN
+    with pytest.raises(K_.B.AsdError):                                  # K*S > 1024 staged granules
+        run_gpu_verify(case, splits=32)
+    lg = torch.zeros((1, 65, 16), dtype=torch.bfloat16, device="cuda")
+    ws = K_.VerifyWorkspace(1, 64, 16)
+    with pytest.raises(K_.B.AsdError):                                  # K > 64
+        K_.verify_accept(lg, torch.zeros((1, 65), dtype=torch.int32, device="cuda"),
+                         torch.zeros((1, 65), device="cuda"), torch.ones((1, 65), device="cuda"), ws)
+    with pytest.raises(ValueError):                                     # no CPU path
+        K_.verify_accept(lg.cpu(), torch.zeros((1, 65), dtype=torch.int32), torch.zeros((1, 65)),
+                         torch.ones((1, 65)), ws)
+
+
+def test_deterministic_and_workspace_reuse(K_):
+    """Tickets are reset by the last arriver: one workspace, many calls, bit-identical outputs."""
+    import torch
+    case = make_verify_case(16, 8, 32000, O.DT_BF16, seed=11)
+    lg = to_device_logits(case["logits"], case["dtype"]).view(16, 8, 32000)
+    ws = K_.VerifyWorkspace(16, 8, 32000)
+    tok = torch.from_numpy(case["tok"]).cuda()
+    lp_d = torch.from_numpy(case["lp_d"]).cuda()
+    u = torch.from_numpy(case["u"]).cuda()
+    first = None
+    for it in range(40):
+        r = K_.verify_accept(lg, tok, lp_d, u, ws)
+        cur = (r.lp_target.clone(), r.accept.clone(), r.n_acc.clone(), r.accept_bits.clone())
+        if first is None:
+            first = cur
+        else:
+            for a, b in zip(first, cur):
+                assert torch.equal(a, b), it
+    torch.cuda.synchronize()
+    assert int(ws.buf[: 16 * 4].view(torch.int32).abs().sum()) == 0      # tickets back to zero
+    got = dict(lp_t=first[0].cpu().numpy(), accept=first[1].cpu().numpy(), n_acc=first[2].cpu().numpy(),
+               bits=first[3].cpu().numpy().view(np.uint64))
+    assert_verify_matches(got, case["ref"])
+    # a smaller batch reuses the same workspace
+    r = K_.verify_accept(lg[:3, :5].contiguous(), tok[:3, :5].contiguous(), lp_d[:3, :5].contiguous(),
+                         u[:3, :5].contiguous(), ws)
+    assert np.array_equal(r.accept.cpu().numpy(), case["ref"]["accept"][:3, :5])
+
+
+def test_edge_cases_follow_the_oracle():
+    """Out-of-range tokens, u = 0, masked (-inf) vocabulary, +inf, NaN and all -inf rows."""
+    B, K, V = 4, 6, 3000
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((B * K, V)) * 4).astype(np.float32)
+    x[1, 100:2900] = -np.inf            # top-p style mask
+    x[2, :] = -np.inf                   # nothing survives
+    x[3, 17] = np.inf
+    x[4, 5] = np.nan
+    x[5, :8] = -np.inf                  # a whole 16-byte vector of -inf at the row start
+    tok = rng.integers(0, V, (B, K)).astype(np.int32)
+    tok.reshape(-1)[0] = -1             # below the vocabulary
+    tok.reshape(-1)[1] = V              # above the vocabulary
+    tok.reshape(-1)[3] = 17             # the +inf logit itself
+    lp_d = -np.abs(rng.standard_normal((B, K))).astype(np.float32)
+    lp_d[3, 0] = -np.inf                # draft probability 0
+    u = rng.uniform(0.05, 1, (B, K)).astype(np.float32)
+    u[0, 0] = 0.0
+    u[3, 1] = 0.0
+    for dtype in (O.DT_F32, O.DT_BF16, O.DT_F16):
+        from tests.helpers import encode_logits
+        store = encode_logits(x, dtype)
+        ref = O.verify_accept(store, dtype, tok, lp_d, u, B, K, V)
+        case = dict(B=B, K=K, V=V, dtype=dtype, ld=V, logits=store, tok=tok, lp_d=lp_d, u=u)
+        with np.errstate(all="ignore"):
+            got = run_gpu_verify(case)
+            # rows whose margin is tiny are not part of the bit-parity set
+            ok = ~(ref["margin"] < 1e-4)
+            assert_verify_matches(got, ref, check_mask=False)
+            assert np.array_equal(got["accept"][ok], ref["accept"][ok])
+        assert got["accept"].reshape(-1)[0] == 1 and np.isneginf(got["lp_t"].reshape(-1)[0])  # u=0 accepts
+        assert np.isnan(got["lp_t"].reshape(-1)[2]) and got["accept"].reshape(-1)[2] == 0
+        assert np.isnan(got["lp_t"].reshape(-1)[4]) and got["accept"].reshape(-1)[4] == 0
+
+
+def test_empty_batch_is_a_noop(K_):
+    import torch
+    ws = K_.VerifyWorkspace(1, 1, 16)
+    lg = torch.zeros((0, 4, 16), dtype=torch.bfloat16, device="cuda")
+    r = K_.verify_accept(lg, torch.zeros((0, 4), dtype=torch.int32, device="cuda"), torch.zeros((0, 4), device="cuda"),
+                         torch.zeros((0, 4), device="cuda"), ws)
+    assert r.n_acc.numel() == 0
+
+
+def test_unfiltered_set_mismatches_only_inside_margin():
+    """No margin filter: any disagreement must sit within 1e-5 of the decision boundary."""
+    rng = np.random.default_rng(77)
+    case = make_verify_case(32, 8, 20000, O.DT_BF16, seed=77, margin=0.0)
+    got = run_gpu_verify(case)
+    diff = got["accept"] != case["ref"]["accept"]
+    print("unfiltered mismatches:", int(diff.sum()), "of", diff.size)
+    assert (case["ref"]["margin"][diff] < LP_ATOL).all()
+
+
+def test_token_logprob_idiom_golden(golden, K_):
+    """A6: the reference's own log(softmax(score)[tok]) values (torch f32, golden fixture)."""
+    import torch
+    g = golden.npz("logprob_idiom.npz")
+    R, V = g["scores"].shape
+    lg = torch.from_numpy(g["scores"]).cuda().view(R, 1, V)
+    ws = K_.VerifyWorkspace(R, 1, V, torch.float32)
+    r = K_.verify_accept(lg, torch.from_numpy(g["tok"]).cuda().view(R, 1), torch.zeros((R, 1), device="cuda"),
+                         torch.full((R, 1), 0.5, device="cuda"), ws)
+    np.testing.assert_allclose(r.lp_target.cpu().numpy()[:, 0], g["logprob"], rtol=1e-6, atol=1e-5)
+
+
+# ---------------------------------------------------------------- size-independent properties
+def test_shift_and_roll_invariance_full_width(K_):
+    """log-softmax is invariant to adding a constant to a row and to rotating the vocabulary
+    (with the token id rotated along); checked at the full 152064 width in f32."""
+    import torch
+    B, K, V = 2, 8, 152064
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((B, K, V), generator=g, device="cuda") * 4
+    tok = torch.randint(0, V, (B, K), generator=g, device="cuda", dtype=torch.int32)
+    lp_d = torch.zeros((B, K), device="cuda")
+    u = torch.full((B, K), 0.5, device="cuda")
+    ws = K_.VerifyWorkspace(B, K, V, torch.float32)
+    base = K_.verify_accept(x, tok, lp_d, u, ws).lp_target.clone()
+    shifted = K_.verify_accept(x + 3.25, tok, lp_d, u, ws).lp_target.clone()
+    rolled = K_.verify_accept(torch.roll(x, 1001, dims=2).contiguous(), ((tok + 1001) % V).to(torch.int32), lp_d, u,
+                              ws).lp_target.clone()
+    assert (base - shifted).abs().max().item() < 2e-5
+    assert (base - rolled).abs().max().item() < 2e-5
+
+
+def test_probabilities_of_a_row_sum_to_one(K_):
+    """Verify every token id of one 4096-wide row: sum_v exp(lp_t[v]) == 1."""
+    import torch
+    V = 4096
+    g = torch.Generator(device="cuda").manual_seed(9)
+    row = (torch.randn((V,), generator=g, device="cuda") * 4).to(torch.bfloat16)
+    lg = row.expand(64, 64, V).contiguous()
+    toks = torch.arange(0, V, device="cuda", dtype=torch.int32).view(64, 64)
+    ws = K_.VerifyWorkspace(64, 64, V)
+    r = K_.verify_accept(lg, toks, torch.zeros((64, 64), device="cuda"), torch.zeros((64, 64), device="cuda"), ws)
+    total = torch.exp(r.lp_target.double()).sum().item()
+    assert abs(total - 1.0) < 1e-4
+    assert int(r.accept.sum()) == V and bool((r.n_acc == 64).all())     # u = 0 accepts every position
+
+
+def test_vocab_sharded_path_matches_single_launch(K_):
+    """asd_lse_partial per shard + asd_accept_from_partials == asd_verify_accept (mask bit-exact)."""
+    import torch
+    case = make_verify_case(8, 8, 152064, O.DT_BF16, seed=31, n_threads=16)
+    B, K, V = 8, 8, 152064
+    lg = to_device_logits(case["logits"], case["dtype"]).view(B, K, V)
+    tok = torch.from_numpy(case["tok"]).cuda()
+    lp_d = torch.from_numpy(case["lp_d"]).cuda()
+    u = torch.from_numpy(case["u"]).cuda()
+    for n_shards in (2, 4, 8):
+        edges = [V * i // n_shards for i in range(n_shards + 1)]
+        ws = K_.VerifyWorkspace(B, K, V)
+        msgs = []
+        for r in range(n_shards):
+            shard = lg[:, :, edges[r]:edges[r + 1]]                  # strided view: ld_row = V
+            msgs.append(K_.lse_partial(shard, tok, edges[r], ws))
+            ref_msg = O.lse_partial(case["logits"].reshape(B * K, V)[:, edges[r]:edges[r + 1]].copy(), O.DT_BF16,
+                                    case["tok"], B, K, edges[r + 1] - edges[r], edges[r])
+            m = msgs[-1].cpu().numpy().astype(np.float64)
+            lse_gpu = np.log(2.0) * (m[..., 0] + np.log2(m[..., 1]))
+            lse_ref = ref_msg[..., 0] + np.log(ref_msg[..., 1])
+            np.testing.assert_allclose(lse_gpu, lse_ref, rtol=1e-6, atol=1e-5)
+            assert np.array_equal(m[..., 2], ref_msg[..., 2])          # gathered logit: exact
+        out = K_.accept_from_partials(torch.stack(msgs).contiguous(), lp_d, u)
+        torch.cuda.synchronize()
+        got = dict(lp_t=out.lp_target.cpu().numpy(), accept=out.accept.cpu().numpy(), n_acc=out.n_acc.cpu().numpy(),
+                   bits=out.accept_bits.cpu().numpy().view(np.uint64))
+        assert_verify_matches(got, case["ref"])
