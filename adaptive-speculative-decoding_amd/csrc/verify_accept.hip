@@ -138,7 +138,8 @@ struct Elem<ASD_DTYPE_F16> {
         float x[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const h2 h = __builtin_bit_cast(h2, v[i]);
+            const uint32_t w = v[i];  // bit_cast of the vector-element lvalue itself reads element 0
+            const h2 h = __builtin_bit_cast(h2, w);
             x[2 * i] = static_cast<float>(h[0]);
             x[2 * i + 1] = static_cast<float>(h[1]);
         }
