@@ -10,6 +10,19 @@
 // 16-byte vectors (online softmax, one rescale per vector), lanes are folded with a fixed
 // xor-butterfly, waves through LDS.
 //
+// Streaming loop.  16-byte buffer loads through a per-slice descriptor whose num_records is the
+// slice end: lanes past the end are dropped by the range check (no memory access), so every batch
+// is issued unconditionally and the loop is software-pipelined (batch i+1 in flight while batch i
+// is reduced; UNROLL..2*UNROLL KiB-loads outstanding per wave).
+//
+// One workgroup per row (S == 1, K <= 32; the regime rows >= CUs).  The row's workgroup finishes
+// its own row: lane 0 prefetches tok / lp_d / u and the drafted token's logit while the row
+// streams, computes lp_t and the accept flag, stores them, and contributes to the sequence's
+// ballot with ONE returning 64-bit atomic add of (1 << 32 | flag << k).  The arrival whose old
+// count is K-1 holds the complete mask: it writes n_acc / accept_bits and zeroes the word.  No
+// payload store, no drain, no read-back on the tail.
+//
+// Split rows (S > 1; few rows, many CUs).
 // Hand-off.  The slice result is published as ONE 8-byte granule (write-through, agent scope),
 // the publishing lane drains its store (s_waitcnt vmcnt(0)) and takes a ticket on the
 // sequence's counter.  The workgroup whose ticket is the last of the sequence's K*S tickets
@@ -19,7 +32,9 @@
 // accept mask / accepted-prefix length with one wave ballot.  Nothing spins: there is no wait
 // anywhere in the kernel.  Granule regions are per sequence and padded to whole 256-byte blocks,
 // so every line of them has exactly one reader per launch (MI355X_MICROARCH.md, inter-workgroup
-// visibility: sc1 stores + drained ticket + sc1 loads).  The last arriver resets the ticket, so a
+// visibility: sc1 stores + drained ticket + sc1 loads).  Every sequence's ticket / ballot word sits in
+// its own 128-byte line: atomics on one line serialise at the memory side (measured: 32 tickets
+// packed in one line made 4096 arrivals cost 80 us).  The last arriver resets the ticket, so a
 // workspace zeroed once serves every later stream-ordered call (hipGraph-replay safe: no epoch
 // argument, no memset node).
 //
@@ -36,6 +51,8 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr double kLn2d = 0.693147180559945309417232121458;
 constexpr float kSentinel = -1.0e30f;  // "minus infinity" that stays finite under subtraction
 constexpr int kMaxStage = 1024;        // granules one finisher stages in LDS (K*S <= kMaxStage)
+constexpr int kTicketStride = 32;      // u32 units: one 128-byte line per sequence
+constexpr int kFastMaxK = 32;          // ballot-by-atomic packs K flags + a 32-bit count in one u64
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -52,10 +69,10 @@ struct VerifyParams {
     int32_t* n_acc;
     uint64_t* bits;
     float* msg;
-    uint32_t* tickets;
+    uint32_t* tickets;   // one 128-byte line per sequence: u32 ticket at +0, u64 ballot word at +8
     uint64_t* granules;
-    uint32_t region;  // granules per sequence region
-    int mode;         // 0: accept, 1: emit (m2, s, g) partials
+    uint32_t region;     // granules per sequence region
+    int mode;            // 0: accept, 1: emit (m2, s, g) partials
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -163,21 +180,32 @@ struct Elem<ASD_DTYPE_F32> {
     }
 };
 
+// 16-byte buffer load; lanes whose offset is >= the descriptor's num_records return 0 without a
+// memory access.  aux: 0 = default cache policy, 2 = nt (streamed, read-once data).
 template <bool NT>
-__device__ __forceinline__ u32x4 load16(const u32x4* p) {
-    if (NT) return __builtin_nontemporal_load(p);
-    return *p;
+__device__ __forceinline__ u32x4 load16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, NT ? 2 : 0));
+}
+
+// log2(x) for x >= 0 with ~1e-7 ABSOLUTE error at any magnitude: exponent exactly, v_log_f32 on
+// the mantissa only, summed in f64.  x == 0 -> -inf; inf / NaN / negative propagate like log2f.
+__device__ __forceinline__ double log2_split(float x) {
+    if (!(x > 0.0f) || !(x < INFINITY)) return static_cast<double>(__builtin_amdgcn_logf(x));
+    int e;
+    const float mant = frexpf(x, &e);
+    return static_cast<double>(e) + static_cast<double>(__builtin_amdgcn_logf(mant));
 }
 
 // lse, log-prob and acceptance test of one row from its combined (m2, s) and gathered logit.
-// f64 for the K-per-sequence epilogue only: it mirrors the oracle's structure, so the only
-// difference left between the two is the f32 accumulation of s.
+// The sums are f64 (they mirror the oracle's structure); the two logarithms are split into an
+// exact exponent and a v_log_f32 of the mantissa, which keeps their absolute error ~1e-7 without
+// a software f64 log on the kernel's tail.
 __device__ __forceinline__ bool finish_row(float m2, float s, float x_tok, float lp_d, float u,
                                            float& lp_out) {
-    const double lse = kLn2d * (static_cast<double>(m2) + log2(static_cast<double>(s)));
+    const double lse = kLn2d * (static_cast<double>(m2) + log2_split(s));
     const double lp = static_cast<double>(x_tok) - lse;
     lp_out = static_cast<float>(lp);
-    const double lu = log(static_cast<double>(u));  // u == 0 -> -inf, u < 0 -> NaN (rejects)
+    const double lu = kLn2d * log2_split(u);  // u == 0 -> -inf (accepts), u < 0 -> NaN (rejects)
     return lu <= lp - static_cast<double>(lp_d);
 }
 
@@ -192,10 +220,26 @@ __device__ __forceinline__ void finish_sequence(bool flag, int lane, int K, int 
     }
 }
 
+template <int DT, int UNROLL, int THREADS, bool CHECK>
+__device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, uint32_t end, float& m2, float& s) {
+    using E = Elem<DT>;
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) {
+        u32x4 v = r[j];
+        if (CHECK) {  // past the slice end the range check returned zeros: make them -inf
+            const bool ok = off + static_cast<uint32_t>(j) * THREADS * 16u < end;
+            const u32x4 neg = {E::kNegInfWord, E::kNegInfWord, E::kNegInfWord, E::kNegInfWord};
+            v = ok ? v : neg;
+        }
+        E::accum(v, m2, s);
+    }
+}
+
 template <int DT, int THREADS, int UNROLL, bool NT>
 __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     using E = Elem<DT>;
     constexpr int kWaves = THREADS / 64;
+    constexpr uint32_t kBatchBytes = static_cast<uint32_t>(UNROLL) * THREADS * 16u;
     __shared__ float red_m[kWaves];
     __shared__ float red_s[kWaves];
     __shared__ uint64_t stage[kMaxStage];
@@ -216,9 +260,18 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     if (head > p.V) head = p.V;
     const int nvec = (p.V - head) / E::kPerVec;
     const int tail = p.V - head - nvec * E::kPerVec;
-    const u32x4* vec = reinterpret_cast<const u32x4*>(rowp + static_cast<int64_t>(head) * E::kBytes);
+    const char* body = rowp + static_cast<int64_t>(head) * E::kBytes;
     const int v0 = static_cast<int>(static_cast<int64_t>(nvec) * split / S);
     const int v1 = static_cast<int>(static_cast<int64_t>(nvec) * (split + 1) / S);
+
+    // the row's own scalars, fetched by lane 0 under the stream (one workgroup per row only)
+    const bool own_row = (S == 1) && (p.mode == 1 || p.K <= kFastMaxK);
+    float x_tok = -INFINITY, lpd = 0.0f, uu = 1.0f;
+    int64_t t_tok = -1;
+    if (own_row && tid == 0) {
+        t_tok = static_cast<int64_t>(p.tok[row]) - p.v_offset;
+        if (p.mode == 0) { lpd = p.lp_d[row]; uu = p.u[row]; }
+    }
 
     float m2 = kSentinel, s = 0.0f;
 
@@ -227,34 +280,48 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     if (split == S - 1 && tid < tail)
         accum_scalar(E::scalar(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + tid), m2, s);
 
-    int i = v0 + tid;
-    for (; i + (UNROLL - 1) * THREADS < v1; i += UNROLL * THREADS) {
-        u32x4 r[UNROLL];
+    if (v1 > v0) {
+        // descriptor over [body + v0*16, body + v1*16): block-uniform, so it lives in SGPRs
+        const uint32_t end = static_cast<uint32_t>(v1 - v0) * 16u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(body) + static_cast<int64_t>(v0) * 16, 0, static_cast<int>(end), 0x00020000);
+        const uint32_t n_full = end / kBatchBytes;                       // batches with every lane in range
+        const uint32_t n_all = (end + kBatchBytes - 1) / kBatchBytes;
+        uint32_t off = static_cast<uint32_t>(tid) * 16u;
+        u32x4 ra[UNROLL], rb[UNROLL];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) r[j] = load16<NT>(vec + i + j * THREADS);
+        for (int j = 0; j < UNROLL; ++j) ra[j] = load16<NT>(rsrc, off + static_cast<uint32_t>(j) * THREADS * 16u);
+        if (own_row && tid == 0 && t_tok >= 0 && t_tok < p.V) x_tok = E::scalar(rowp, t_tok);
+        uint32_t bi = 0;
+        while (true) {  // ping-pong: ra holds batch bi, rb receives batch bi+1 (and vice versa)
+            if (bi + 1 < n_all) {
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) E::accum(r[j], m2, s);
-    }
-    if (i < v1) {  // ragged last batch: predicated loads, still issued back to back
-        u32x4 r[UNROLL];
-#pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
-            const int idx = i + j * THREADS;
-            if (idx < v1) {
-                r[j] = load16<NT>(vec + idx);
-            } else {
-                r[j] = u32x4{E::kNegInfWord, E::kNegInfWord, E::kNegInfWord, E::kNegInfWord};
+                for (int j = 0; j < UNROLL; ++j)
+                    rb[j] = load16<NT>(rsrc, off + kBatchBytes + static_cast<uint32_t>(j) * THREADS * 16u);
             }
-        }
+            if (bi < n_full) consume<DT, UNROLL, THREADS, false>(ra, off, end, m2, s);
+            else consume<DT, UNROLL, THREADS, true>(ra, off, end, m2, s);
+            off += kBatchBytes;
+            if (++bi >= n_all) break;
+            if (bi + 1 < n_all) {
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) E::accum(r[j], m2, s);
+                for (int j = 0; j < UNROLL; ++j)
+                    ra[j] = load16<NT>(rsrc, off + kBatchBytes + static_cast<uint32_t>(j) * THREADS * 16u);
+            }
+            if (bi < n_full) consume<DT, UNROLL, THREADS, false>(rb, off, end, m2, s);
+            else consume<DT, UNROLL, THREADS, true>(rb, off, end, m2, s);
+            off += kBatchBytes;
+            if (++bi >= n_all) break;
+        }
+    } else if (own_row && tid == 0 && t_tok >= 0 && t_tok < p.V) {
+        x_tok = E::scalar(rowp, t_tok);
     }
 
     // lanes -> wave (fixed xor butterfly), waves -> workgroup (LDS)
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float om = __shfl_xor(m2, off, 64);
-        const float os = __shfl_xor(s, off, 64);
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float om = __shfl_xor(m2, o, 64);
+        const float os = __shfl_xor(s, o, 64);
         ms_merge(m2, s, om, os);
     }
     if (kWaves > 1) {
@@ -266,16 +333,46 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
 #pragma unroll
         for (int w = 1; w < kWaves; ++w) ms_merge(m2, s, red_m[w], red_s[w]);
     }
+    // only wave 0 is left here
 
-    // publish the slice, take a ticket; only wave 0 is left here
+    if (own_row) {
+        // ---- one workgroup per row: finish the row here ---------------------------------------
+        if (lane != 0) return;
+        if (p.mode == 1) {
+            p.msg[3 * row + 0] = m2;
+            p.msg[3 * row + 1] = s;
+            p.msg[3 * row + 2] = x_tok;
+            return;
+        }
+        float lp;
+        const bool flag = finish_row(m2, s, x_tok, lpd, uu, lp);
+        p.lp_t[row] = lp;
+        p.accept[row] = flag ? 1 : 0;
+        // ballot by atomic: count in the high word, this row's flag at bit k of the low word
+        uint64_t* word = reinterpret_cast<uint64_t*>(p.tickets + static_cast<int64_t>(b) * kTicketStride + 2);
+        const uint64_t mine = (1ull << 32) | (static_cast<uint64_t>(flag ? 1u : 0u) << k);
+        const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (static_cast<uint32_t>(old >> 32) == static_cast<uint32_t>(p.K - 1)) {
+            const uint32_t mask = static_cast<uint32_t>(old | mine);
+            const uint32_t inv = ~mask;
+            const int n = inv ? __builtin_ctz(inv) : 32;
+            p.n_acc[b] = n < p.K ? n : p.K;
+            if (p.bits) p.bits[b] = mask;
+            __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    // ---- split rows: publish the slice, take a ticket ------------------------------------------
     const int KS = p.K * S;
     uint64_t* region = p.granules + static_cast<int64_t>(b) * p.region;
+    uint32_t* ticket = p.tickets + static_cast<int64_t>(b) * kTicketStride;
     int last = 0;
     if (lane == 0) {
         const uint64_t g = (static_cast<uint64_t>(__float_as_uint(s)) << 32) | __float_as_uint(m2);
         __hip_atomic_store(region + k * S + split, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t old = __hip_atomic_fetch_add(p.tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = (old == static_cast<uint32_t>(KS - 1));
     }
     last = __shfl(last, 0, 64);
@@ -283,7 +380,6 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
 
     // ---- last arriver of sequence b: finish its K rows ------------------------------------
     const int frow = b * p.K + lane;  // lane <-> draft position
-    float x_tok = -INFINITY, lpd = 0.0f, uu = 1.0f;
     if (lane < p.K) {
         const int64_t t = static_cast<int64_t>(p.tok[frow]) - p.v_offset;
         if (t >= 0 && t < p.V)
@@ -303,7 +399,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
             ms_merge(fm, fs, __uint_as_float(static_cast<uint32_t>(g)), __uint_as_float(static_cast<uint32_t>(g >> 32)));
         }
     }
-    if (lane == 0) __hip_atomic_store(p.tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     if (p.mode == 1) {
         if (lane < p.K) {
@@ -424,7 +520,7 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     if (g.nt < 0) g.nt = h.nt;
     if (g.splits > max_splits_for(p.K)) return ASD_ERR_UNSUPPORTED;
 
-    const size_t ticket_bytes = round_up(static_cast<size_t>(p.B) * sizeof(uint32_t), 256);
+    const size_t ticket_bytes = round_up(static_cast<size_t>(p.B) * kTicketStride * sizeof(uint32_t), 256);
     const size_t region_bytes = round_up(static_cast<size_t>(p.K) * g.splits * sizeof(uint64_t), 256);
     if (workspace_bytes < ticket_bytes + region_bytes * static_cast<size_t>(p.B)) return ASD_ERR_WORKSPACE;
     p.S = g.splits;
@@ -454,7 +550,7 @@ ASD_EXPORT size_t asd_verify_accept_workspace_bytes(int B, int K, int V, int dty
     (void)V;
     (void)dtype;
     if (B <= 0 || K <= 0) return 256;
-    const size_t ticket_bytes = round_up(static_cast<size_t>(B) * sizeof(uint32_t), 256);
+    const size_t ticket_bytes = round_up(static_cast<size_t>(B) * kTicketStride * sizeof(uint32_t), 256);
     const size_t region_bytes = round_up(static_cast<size_t>(K) * max_splits_for(K) * sizeof(uint64_t), 256);
     return ticket_bytes + region_bytes * static_cast<size_t>(B);
 }
