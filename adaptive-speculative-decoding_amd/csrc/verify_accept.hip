@@ -453,15 +453,21 @@ struct Geometry {
     int splits, threads, unroll, nt;
 };
 
-// Launch geometry.  Rows are independent, so the only questions are how many workgroups share a
-// row and how many 16-byte loads each lane keeps in flight.  Policy ("verify kernel
-// geometry"; numbers from the gpurun sweeps under profiles/):  aim for ~8 workgroups of 256
-// lanes per CU, never cut a slice below one full unrolled batch per workgroup.
+// Launch geometry (numbers: profiles/r01_sweep_*.json, MI355X, 256 CUs).
+//   rows >= CUs : one workgroup per row, no split.  1024 lanes x 2-deep batches when every CU gets
+//                 exactly one row-sized workgroup, 512 lanes x 4 when rows queue up behind each other
+//                 (B=32: 16.8 us, B=128: 51.7 us = 6.0 TB/s).
+//   rows <  CUs : split rows until ~2 workgroups of 256 lanes per CU exist (B=8: S=8, 9.6 us); a slice
+//                 is never cut below one full batch per workgroup.
 Geometry choose_geometry(int R, int K, int V, int dtype, int cus) {
-    Geometry g{1, 256, 4, 1};
+    Geometry g{1, 1024, 2, 1};
+    if (R > cus) { g.threads = 512; g.unroll = 4; }
+    if (R >= cus) return g;
+    g.threads = 256;
+    g.unroll = 2;
     const int64_t row_vecs = static_cast<int64_t>(V) * dtype_size(dtype) / 16;
     const int64_t batch = static_cast<int64_t>(g.threads) * g.unroll;
-    int64_t want = (static_cast<int64_t>(cus) * 8 + R - 1) / (R > 0 ? R : 1);
+    int64_t want = (static_cast<int64_t>(cus) * 2 + R - 1) / (R > 0 ? R : 1);
     int64_t cap = row_vecs / batch;
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
