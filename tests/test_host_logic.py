@@ -1,0 +1,328 @@
+"""Host-side logic of the package (reference-API mirrors) on CPU, with the oracle injected as the
+backend (tests/oracle_backend.py).  What is checked here is control flow, signatures, error
+behaviour and the pure-host arithmetic (A9, A12, closed forms) against the goldens; the GPU
+arithmetic itself is covered by the -m gpu tests."""
+import asyncio
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+import asd_amd
+from asd_amd.algorithms import (AdaptiveStopping, OptimalStoppingTable, bayesian_adjustment, compute_expected_cost,
+                                optimal_stopping_rule, optimal_stopping_rule_batch)
+from asd_amd.minimal_adaptive_decoder import (DecodingResult, MinimalAdaptiveDecoder, MinimalQualityPredictor,
+                                              SimpleTokenizer, features_from_token_ids, train_minimal_predictor)
+from asd_amd.serving import AdaptiveSpeculativePipeline, PipelineConfig, RequestCache, RequestResult
+from asd_amd.theory import OptimalStoppingTheory, RegretAnalyzer, TheoreticalParameters
+from asd_amd.training import extract_features, extract_features_batch, token_logprobs
+from oracle import oracle as O
+from tests.oracle_backend import OracleBackend
+
+
+@pytest.fixture(autouse=True)
+def oracle_backend():
+    asd_amd.set_backend(OracleBackend())
+    yield
+    asd_amd.set_backend(None)
+
+
+# ------------------------------------------------------------------------- dp_solver API
+def test_dp_solver_signatures_and_errors(golden):
+    k, J = optimal_stopping_rule([.3, .5, .8, 1], [1, 1.6, 4.2, 8.8], 100)
+    assert (k, J) == (3, [15.6, 14.6, 13.0, 8.8, 0.0]) and isinstance(k, int) and isinstance(J, list)
+    with pytest.raises(ValueError, match="same length"):
+        optimal_stopping_rule([0.5, 0.5], [1.0], 1.0)
+    with pytest.raises(ValueError):
+        optimal_stopping_rule_batch([[0.5, 0.5]], [1.0], 1.0)
+    assert bayesian_adjustment(0.9, 1000, 2, 2) == 0.898406374501992
+    g = golden.npz("dp_rule.npz")
+    for i in (0, 17, 400, 1599):
+        L = int(g["L"][i])
+        p, c = [float(x) for x in g["p"][i, :L]], [float(x) for x in g["C"][i, :L]]
+        k, J = optimal_stopping_rule(p, c, float(g["lam"][i]), bool(g["risk"][i]), float(g["alpha"][i]),
+                                     float(g["beta"][i]))
+        assert k == int(g["k_star"][i]) and J == g["J"][i, :L + 1].tolist()
+        assert compute_expected_cost(p, c, float(g["lam"][i]), int(g["k_star"][i])) == float(g["cost_at_kstar"][i])
+
+
+def test_table_and_adaptive_stopping_goldens(golden):
+    g = golden.json("a4_table_adaptive.json")
+    tab = OptimalStoppingTable(g["lambdas"], 4)
+    tab.precompute(g["cost"], g["grid"])
+    assert set(tab.table) == set(g["lambdas"])
+    for q in g["lookups"]:
+        assert tab.lookup(q["p"], q["lam"]) == q["k"]
+        assert tab.lookup(q["p"], q["lam"], fallback_to_dp=False) == q["k_nofallback"]
+    ad = AdaptiveStopping(initial_lambda=0.7, confidence_level=0.1)
+    for st, q, lat in g["updates"]:
+        ad.update_statistics(int(st), q, lat)
+    assert ad.stage_counts.tolist() == g["counts"] and ad.stage_rewards.tolist() == g["rewards"]
+    assert [[float(x) for x in ad.get_confidence_bounds(s)] for s in range(4)] == g["bounds"]
+    assert [ad.should_explore(s) for s in range(4)] == g["explore"]
+    fresh = AdaptiveStopping()
+    assert [str(x) for x in fresh.get_confidence_bounds(0)] == g["fresh_bounds"]
+    assert fresh.should_explore(2) == g["fresh_explore"]
+
+
+# ------------------------------------------------------------------------- theory API
+def test_theory_thresholds_and_closed_forms(golden):
+    g = golden.json("thresholds.json")
+    for row in g["rows"]:
+        t = OptimalStoppingTheory(TheoreticalParameters(n_stages=len(row["q"]), quality_bounds=list(row["q"]),
+                                                        cost_ratios=list(row["c"]), lambda_param=row["lam"]))
+        pol = t.derive_optimal_policy()
+        assert [float(pol[s]) for s in range(len(row["q"]))] == row["theta"]
+        assert list(pol) == list(range(len(row["q"]) - 1, -1, -1))       # reference dict order
+        assert t.thresholds_array().tolist() == row["theta"]
+    m = g["misc"]
+    t = OptimalStoppingTheory(TheoreticalParameters(lambda_param=1.0))
+    assert t.params.quality_bounds == [0.7, 0.8, 0.85, 0.9] and t.params.cost_ratios == [1.0, 2.0, 4.5, 10.0]
+    assert [float(t.derive_optimal_policy()[s]) for s in range(4)] == m["default_theta"]
+    for T, want in m["regret_bound"].items():
+        assert float(t.compute_regret_bound(int(T))) == want
+    assert t.sample_complexity() == m["sample_complexity"]
+    assert t._compute_improvement_probability(1) == 0.6 * (1 - 0.8)
+    ra = RegretAnalyzer(t)
+    for s, d, want in m["instant_regret"]:
+        assert float(ra.compute_instantaneous_regret(s, d)) == want
+    assert float(ra.compute_cumulative_regret()) == m["cumulative"]
+    assert float(ra.compute_average_regret()) == m["average"]
+    assert {k: float(v) for k, v in ra.theoretical_vs_empirical().items()} == m["tve"]
+    assert RegretAnalyzer(t).compute_average_regret() == 0.0
+
+
+# ------------------------------------------------------------------------- minimal decoder
+@pytest.fixture
+def decoder(tmp_path, golden):
+    cfg = golden.json("decoder_misc.json")["config"]
+    for i, s in enumerate(cfg["models"]["stages"]):
+        s["model_path"] = f"local/stage{i}"
+    path = tmp_path / "models.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    g = golden.npz("predictor.npz")
+    import torch
+    pred = MinimalQualityPredictor()
+    pred.load_state_dict({"net.0.weight": torch.from_numpy(g["w1"]), "net.0.bias": torch.from_numpy(g["b1"]),
+                          "net.3.weight": torch.from_numpy(g["w2"]), "net.3.bias": torch.from_numpy(g["b2"])})
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        yield MinimalAdaptiveDecoder(str(path), predictor=pred)
+    finally:
+        os.chdir(cwd)
+
+
+def test_decoder_features_a9_and_heuristics_a12(golden, decoder):
+    g = golden.json("decoder_misc.json")
+
+    class Tok:
+        def __init__(self, ids):
+            self.ids = ids
+
+        def encode(self, prompt, return_tensors="pt"):
+            import torch
+            return torch.tensor([self.ids], dtype=torch.int64)
+
+    for rec in g["a9"]:
+        f = decoder.predictor.extract_features(rec["prompt"], Tok(rec["ids"]))
+        assert f.dtype.is_floating_point and f.shape == (64,)
+        assert f.tolist() == rec["features"]
+        assert features_from_token_ids(rec["ids"], rec["prompt"]).tolist() == rec["features"]
+    for rec in g["a12"]:
+        d = decoder._estimate_difficulty(rec["prompt"])
+        assert d == rec["difficulty"]
+        assert [float(decoder._compute_regret(s, d)) for s in range(4)] == rec["regret"]
+
+
+def test_decoder_decode_matches_golden_picks(golden, decoder):
+    g = golden.npz("predictor.npz")
+    picks = golden.json("threshold_picks.json")
+    assert len(decoder.models) == 4 and isinstance(decoder.tokenizer, SimpleTokenizer)
+    assert decoder.predictor.training is False
+    scores = decoder._scores(g["X"])
+    np.testing.assert_allclose(scores, g["scores"], atol=1e-6, rtol=0)
+    for lam, rec in picks.items():
+        decoder.set_lambda(float(lam))
+        assert decoder._theta_vector().tolist() == rec["theta"]
+        got = asd_amd.get_backend().threshold_stop(g["scores_one_by_one"].astype(np.float32), decoder._theta_vector())
+        assert got.tolist() == rec["stage"]
+    decoder.set_lambda(0.1)
+    res = decoder.decode("What is the capital of France?", max_tokens=10)
+    assert isinstance(res, DecodingResult) and 0 <= res.selected_stage < 4
+    assert res.text == f"[Generated with Qwen3-{['7b', '14b', '32b', '72b'][res.selected_stage]}]"
+    batch = decoder.decode_batch(["hi", "why is the sky blue?", "x " * 300])
+    assert [r.selected_stage for r in batch] == [decoder.decode(p).selected_stage for p in ["hi", "why is the sky blue?", "x " * 300]]
+    assert decoder.decode_batch([]) == []
+
+
+def test_predictor_module_eval_train_and_training_loop(tmp_path, golden):
+    import torch
+    g = golden.npz("predictor.npz")
+    pred = MinimalQualityPredictor()
+    assert sorted(pred.state_dict()) == ["net.0.bias", "net.0.weight", "net.3.bias", "net.3.weight"]
+    pred.load_state_dict({"net.0.weight": torch.from_numpy(g["w1"]), "net.0.bias": torch.from_numpy(g["b1"]),
+                          "net.3.weight": torch.from_numpy(g["w2"]), "net.3.bias": torch.from_numpy(g["b2"])})
+    pred.eval()
+    out = pred(torch.from_numpy(g["X"]))
+    assert out.shape == (256, 1)
+    np.testing.assert_allclose(out.numpy()[:, 0], g["scores"], atol=1e-6, rtol=0)
+    assert pred(torch.from_numpy(g["X"][3])).shape == (1,)
+    data = [{"features": torch.rand(8, 64), "quality_labels": torch.rand(8, 1).round()} for _ in range(3)]
+    trained = train_minimal_predictor(data, data[:1], epochs=2, save_path=str(tmp_path / "ck" / "p.pt"))
+    assert (tmp_path / "ck" / "p.pt").exists() and trained.training is False
+
+
+# ------------------------------------------------------------------------- A6 / A7
+def test_extract_features_matches_reference_goldens(golden):
+    g = golden.npz("features_a7.npz")
+    meta = golden.json("features_a7_meta.json")
+    mds = []
+    for i, m in enumerate(meta):
+        n = int(g["n_valid"][i])
+        mds.append({"logprobs": [float(x) for x in g["logprobs"][i, :n]], "generation_time": m["generation_time"],
+                    "completion_tokens": m["completion_tokens"]})
+    got = extract_features_batch([m["prompt"] for m in meta], [m["output"] for m in meta], mds,
+                                 [m["stage_id"] for m in meta])
+    assert got.tobytes() == g["features"].tobytes()
+    one = extract_features(meta[7]["prompt"], meta[7]["output"], mds[7], meta[7]["stage_id"])
+    assert one == g["features"][7].tolist() and len(one) == 64
+
+
+def test_token_logprobs_matches_reference_idiom(golden):
+    g = golden.npz("logprob_idiom.npz")
+    lp = token_logprobs(g["scores"], g["tok"])
+    np.testing.assert_allclose(lp, g["logprob"], rtol=1e-6, atol=1e-5)
+
+
+# ------------------------------------------------------------------------- pipeline
+class FakeStage:
+    def __init__(self, name, cost):
+        self.name, self.cost_per_token, self.calls = name, cost, []
+
+    def generate(self, prompts, max_tokens, temperature, return_logprobs=True):
+        self.calls.append(list(prompts))
+        texts = [f"{self.name} answer to <{p[:12]}>" for p in prompts]
+        return texts, [np.array([-0.1, -0.2, -0.3]) for _ in prompts], {"generation_time_ms": 1.0}
+
+    def get_model_info(self):
+        return {"name": self.name}
+
+
+class FakeStageManager:
+    def __init__(self, costs=(1.0, 1.6, 4.2, 8.8), names=("8b", "13b", "34b", "70b")):
+        self.stages = {n: FakeStage(n, c) for n, c in zip(names, costs)}
+
+    def get_stage(self, name):
+        return self.stages[name]
+
+
+class ScriptedPredictor:
+    """p depends on the prompt's first word and the stage: 'easy' -> high, 'hard' -> low."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def predict(self, prompt, draft_output, draft_logprobs, stage_id, feature_extractor):
+        self.calls += 1
+        base = {"easy": 0.97, "mid": 0.6, "hard": 0.05}.get(prompt.split()[0], 0.5)
+        return min(0.99, base + 0.2 * stage_id)
+
+
+def _pipeline(stop_rule, lam=1.0, **kw):
+    sm = FakeStageManager()
+    cfg = PipelineConfig(lambda_value=lam, stop_rule=stop_rule, **kw)
+    return AdaptiveSpeculativePipeline(sm, ScriptedPredictor(), object(), cfg), sm
+
+
+def test_prefix_rule_reproduces_reference_trace():
+    """with the reference's prefix DP every request stops at stage 0 with
+    stage_probabilities = [bayes(p0)] and stage_costs = [C0]."""
+    pipe, sm = _pipeline("prefix", lam=50.0)
+    for word in ("easy", "mid", "hard"):
+        r = pipe.process_request(f"{word} question")
+        assert isinstance(r, RequestResult)
+        assert r.stopped_at_stage == 0 and r.stage_costs == [1.0]
+        p0 = {"easy": 0.97, "mid": 0.6, "hard": 0.05}[word]
+        n_obs = max(100, pipe.stats["total_requests"] - 1)
+        assert r.stage_probabilities == [O.py_bayesian_adjustment(p0, n_obs, 1.0, 1.0)]
+        assert r.output.startswith("8b answer")
+    assert len(sm.stages["13b"].calls) == 0
+    pipe.shutdown()
+
+
+def test_full_rule_follows_the_dp_over_all_stages():
+    pipe, sm = _pipeline("full", lam=30.0, risk_adjustment=False)
+    res = pipe.batch_process(["easy one", "hard one", "mid one", "hard two"])
+    costs = [1.0, 1.6, 4.2, 8.8]
+    for r, word in zip(res, ("easy", "hard", "mid", "hard")):
+        base = {"easy": 0.97, "mid": 0.6, "hard": 0.05}[word]
+        probs, stop = [], None
+        for i in range(4):
+            probs.append(1.0 if i == 3 else min(0.99, base + 0.2 * i))
+            P = [1.0] * 4
+            P[:i + 1] = probs
+            k, _ = O.py_optimal_stopping_rule(P, costs, 30.0)
+            if k <= i or i == 3:
+                stop = k
+                break
+        assert r.stopped_at_stage == stop
+        assert r.stage_probabilities == probs and r.stage_costs == costs[:stop + 1]
+        assert r.total_tokens > 0 and r.latency_ms >= 0
+    # batching: one generate() call per stage, shrinking as requests stop
+    assert [len(c) for c in sm.stages["8b"].calls] == [4]
+    assert all(len(c) <= 4 for c in sm.stages["13b"].calls) and len(sm.stages["13b"].calls) <= 1
+    st = pipe.get_stats()
+    assert st["total_requests"] == 4 and sum(st["stage_stops"]) == 4
+    for key in ("stage_distribution", "avg_tokens_per_request", "cache_stats", "active_requests", "avg_latency",
+                "avg_tokens_per_second", "total_tokens", "avg_stage_probabilities", "error_count"):
+        assert key in st
+    pipe.update_lambda(0.01)
+    assert pipe.config.lambda_value == 0.01
+    assert pipe.process_request("hard again").stopped_at_stage == 0       # quality is cheap now
+    pipe.reset_stats()
+    assert pipe.get_stats()["total_requests"] == 0
+    pipe.warmup(3)
+    assert pipe.get_stats()["total_requests"] == 3
+    r = asyncio.run(pipe.process_request_async("easy async", request_id="abc"))
+    assert r.request_id == "abc"
+    pipe.shutdown()
+
+
+def test_pipeline_errors_are_counted_and_reraised():
+    pipe, sm = _pipeline("full")
+
+    def boom(**kw):
+        raise RuntimeError("stage down")
+
+    sm.stages["8b"].generate = boom
+    with pytest.raises(RuntimeError, match="stage down"):
+        pipe.process_request("easy x")
+    assert pipe.stats["error_count"] == 1 and pipe.active_requests == {}
+    with pytest.raises(ValueError):
+        AdaptiveSpeculativePipeline(sm, ScriptedPredictor(), None, PipelineConfig(stop_rule="nope"))
+    pipe.shutdown()
+
+
+def test_request_cache_surface_and_cache_hits():
+    c = RequestCache(max_entries=3)
+    assert c.get_cache("r", 0) is None
+    assert c.allocate("r", 0, {"output": "a", "logprobs": np.array([])})
+    c.allocate("r", 1, {"output": "b"})
+    c.allocate("r", 2, {"output": "c"})
+    assert c.get_cache("r", 1)["output"] == "b"
+    c.truncate_at_stage("r", 0)
+    assert c.get_cache("r", 1) is None and c.get_cache("r", 0)["output"] == "a"
+    c.allocate("q", 0, {"output": "z"})
+    c.allocate("q", 1, {"output": "z"})
+    c.allocate("s", 0, {"output": "evicts the oldest request"})
+    st = c.get_stats()
+    assert st["total_allocations"] == 6 and st["evictions"] >= 1
+    c.cleanup_request("q")
+    # a pre-populated cache entry is used instead of generate()
+    pipe, sm = _pipeline("prefix")
+    pipe.cache_manager.allocate("rid", 0, {"output": "cached text", "logprobs": np.array([])})
+    r = pipe.process_request("easy q", request_id="rid")
+    assert r.cache_hits == 1 and r.output == "cached text" and sm.stages["8b"].calls == []
+    pipe.shutdown()
