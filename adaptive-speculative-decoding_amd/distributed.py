@@ -1,0 +1,140 @@
+"""Multi-GPU forms of the verify step: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in the CPU tests).  The reference has no collective of its own
+(TP lives inside vLLM); these are the three placements SURVEY.md §8e derives from
+the north star, and the rule they share is that FULL LOGITS NEVER CROSS A LINK:
+
+  batch-parallel replicas   every rank verifies its own slice of the batch; no data-path
+                            collective at all (optional all-gather of n_acc, 4 B per sequence).
+  tiers on different GPUs   the verify kernel runs where the target logits are produced; the draft
+                            rank ships tok + lp_d ([B,K] i32 + f32 = 2 KB at B=32, K=8) and gets
+                            accept + n_acc back (~400 B): `TierLink`, point-to-point send/recv.
+  vocab-sharded target      each rank reduces its [B,K,V/R] slice to (m2, s, g) triples
+                            (asd_lse_partial), ONE all-gather of [B,K,3] f32 per rank (3 KB at B=32),
+                            then every rank combines them in rank order (asd_accept_from_partials):
+                            `VocabShardedVerifier`.  Moving the logits instead would cost 77.9 MB /
+                            153 GB/s = 0.5 ms per hop against a ~17 us kernel.
+
+The compute is reached through a small `ops` object so that the CPU test-suite can drive the
+exchange logic over gloo with the oracle (tests/oracle_backend.py: OracleOps); the default is the
+HIP kernels and there is no other implementation in this package.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced [start, end) of `total` items for `rank` of `world`."""
+    return total * rank // world, total * (rank + 1) // world
+
+
+class HipOps:
+    """The product: device tensors through libasd_hip.so."""
+
+    def __init__(self):
+        from . import kernels
+        self.K = kernels
+        self._ws = {}
+
+    def _workspace(self, B, K, V, dtype, device):
+        key = (B, K, str(dtype), str(device))
+        ws = self._ws.get(key)
+        if ws is None or ws.V < V:
+            ws = self._ws[key] = self.K.VerifyWorkspace(B, K, V, dtype, device)
+        return ws
+
+    def verify_accept(self, logits, tok, lp_d, u):
+        B, K = tok.shape
+        ws = self._workspace(B, K, logits.shape[-1], logits.dtype, logits.device)
+        r = self.K.verify_accept(logits, tok, lp_d, u, ws)
+        return r.lp_target, r.accept, r.n_acc, r.accept_bits
+
+    def lse_partial(self, logits_shard, tok, v_offset):
+        B, K = tok.shape
+        ws = self._workspace(B, K, logits_shard.shape[-1], logits_shard.dtype, logits_shard.device)
+        return self.K.lse_partial(logits_shard, tok, v_offset, ws)
+
+    def accept_from_partials(self, msg_all, lp_d, u):
+        r = self.K.accept_from_partials(msg_all, lp_d, u)
+        return r.lp_target, r.accept, r.n_acc, r.accept_bits
+
+
+def _world(group) -> Tuple[int, int]:
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+class VocabShardedVerifier:
+    """Target lm_head split over the ranks of `group` along the vocabulary."""
+
+    def __init__(self, vocab: int, ops=None, group=None):
+        self.vocab = vocab
+        self.ops = ops if ops is not None else HipOps()
+        self.group = group
+        self.world, self.rank = _world(group)
+        self.v0, self.v1 = shard_bounds(vocab, self.world, self.rank)
+
+    def verify(self, logits_shard: torch.Tensor, tok: torch.Tensor, lp_d: torch.Tensor, u: torch.Tensor):
+        """logits_shard: [B,K,v1-v0] of THIS rank; tok: GLOBAL ids.  Returns (lp_t, accept, n_acc, bits),
+        identical on every rank (fixed combine order)."""
+        if logits_shard.shape[-1] != self.v1 - self.v0:
+            raise ValueError(f"rank {self.rank} expects a shard of width {self.v1 - self.v0}")
+        msg = self.ops.lse_partial(logits_shard, tok, self.v0).contiguous()
+        parts = [torch.empty_like(msg) for _ in range(self.world)]
+        dist.all_gather(parts, msg, group=self.group)          # the one exchange step: [B,K,3] per rank
+        return self.ops.accept_from_partials(torch.stack(parts).contiguous(), lp_d, u)
+
+
+class BatchShardedVerifier:
+    """Batch-parallel replicas: rank r owns sequences [b0, b1); no data-path collective."""
+
+    def __init__(self, batch: int, ops=None, group=None):
+        self.ops = ops if ops is not None else HipOps()
+        self.group = group
+        self.world, self.rank = _world(group)
+        self.batch = batch
+        self.b0, self.b1 = shard_bounds(batch, self.world, self.rank)
+
+    def verify_local(self, logits, tok, lp_d, u):
+        """Arguments are THIS rank's rows [b0:b1)."""
+        return self.ops.verify_accept(logits, tok, lp_d, u)
+
+    def gather_n_acc(self, n_acc_local: torch.Tensor) -> torch.Tensor:
+        """Optional [B] view of the accepted lengths on every rank (token accounting)."""
+        sizes = [shard_bounds(self.batch, self.world, r) for r in range(self.world)]
+        width = max(e - s for s, e in sizes)
+        pad = torch.zeros(width, dtype=n_acc_local.dtype, device=n_acc_local.device)
+        pad[: n_acc_local.numel()] = n_acc_local
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        return torch.cat([p[: e - s] for p, (s, e) in zip(parts, sizes)])
+
+
+class TierLink:
+    """Point-to-point hand-off between the rank that drafts and the rank that holds the target."""
+
+    def __init__(self, draft_rank: int, target_rank: int, group=None):
+        self.draft_rank, self.target_rank, self.group = draft_rank, target_rank, group
+
+    # draft side --------------------------------------------------------------------------
+    def send_draft(self, tok: torch.Tensor, lp_d: torch.Tensor) -> None:
+        """tok [B,K] i32 + lp_d [B,K] f32 as ONE message (bit-cast into an i32 [2,B,K] buffer)."""
+        buf = torch.stack([tok.to(torch.int32), lp_d.to(torch.float32).view(torch.int32)]).contiguous()
+        dist.send(buf, dst=self.target_rank, group=self.group)
+
+    def recv_verdict(self, B: int, K: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        buf = torch.empty(B * K + B, dtype=torch.int32, device=device)
+        dist.recv(buf, src=self.target_rank, group=self.group)
+        return buf[: B * K].view(B, K).to(torch.uint8), buf[B * K:].clone()
+
+    # target side -------------------------------------------------------------------------
+    def recv_draft(self, B: int, K: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        buf = torch.empty((2, B, K), dtype=torch.int32, device=device)
+        dist.recv(buf, src=self.draft_rank, group=self.group)
+        return buf[0].contiguous(), buf[1].contiguous().view(torch.float32)
+
+    def send_verdict(self, accept: torch.Tensor, n_acc: torch.Tensor) -> None:
+        buf = torch.cat([accept.reshape(-1).to(torch.int32), n_acc.reshape(-1).to(torch.int32)]).contiguous()
+        dist.send(buf, dst=self.draft_rank, group=self.group)

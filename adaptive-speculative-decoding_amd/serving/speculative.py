@@ -1,0 +1,174 @@
+"""Token-level draft -> verify -> accept -> stop loop (the path BASELINE.json's north star names).
+
+The reference has no token-level verification (its "speculative decoding" is a
+model cascade), so this module DEFINES the step, on top of the two kernels that carry the
+arithmetic:
+
+  draft tier   proposes K tokens per sequence, keeping lp_d[b,k] = log q(tok[b,k])
+  target tier  scores the K drafted positions in one forward: logits_t [B, K(+1), V]
+  verify       asd_verify_accept: lp_t, accept[b,k] = log u <= lp_t - lp_d, n_acc[b], ballot word
+  stop         asd_predictor_stop: log-prob statistics of the K target log-probs -> feature columns
+               [5:10] -> quality predictor -> Bayes adjustment -> DP stop rule over the tiers:
+               stop[b] says whether tier `stage_idx`'s verification is final for sequence b or
+               the step should be re-verified by the next (larger) tier.
+  commit       n_acc accepted tokens + one token from the target (residual distribution at the
+               first rejection, or the target's own next-token distribution when all K pass).
+
+`SpeculativeVerifier` is the device-resident state of one (draft tier, target tier) pair: work
+space, packed predictor weights, stage costs, history of adjusted probabilities.  Everything it
+does per step is two launches through the C ABI; no host synchronisation.
+
+`speculative_generate` drives two `SyntheticLM`s through the loop.  That part is PLUMBING (model
+execution is third-party in the reference): plain torch sampling, lock-step commit of
+min_b(n_acc)+1 tokens so the batch shares one KV length.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import synthetic_lm  # noqa: F401  (re-exported for callers)
+from .. import kernels as K
+
+
+@dataclass
+class StepResult:
+    verify: K.VerifyResult
+    stop: Optional[K.StopResult]
+
+
+class SpeculativeVerifier:
+    def __init__(self, batch: int, draft_len: int, vocab: int, *, logits_dtype: torch.dtype = torch.bfloat16,
+                 stage_costs: Sequence[float] = (1.0, 4.5, 10.0), lambda_value: float = 1.0,
+                 risk_adjustment: bool = True, risk_alpha: float = 1.0, risk_beta: float = 1.0, n_obs: int = 100,
+                 predictor=None, stats_col: int = 5, prefix_rule: bool = False, device=None):
+        if draft_len > 64:
+            raise ValueError("draft_len must be <= 64 (one ballot word per sequence)")
+        self.B, self.Kd, self.V = batch, draft_len, vocab
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.ws = K.VerifyWorkspace(batch, draft_len, vocab, logits_dtype, self.device)
+        self.L = len(stage_costs)
+        self.costs = torch.tensor(list(stage_costs), dtype=torch.float64, device=self.device)
+        self.lam, self.risk = float(lambda_value), bool(risk_adjustment)
+        self.alpha, self.beta, self.n_obs = float(risk_alpha), float(risk_beta), int(n_obs)
+        self.stats_col, self.prefix = stats_col, bool(prefix_rule)
+        self.p_hist = torch.ones((batch, self.L), dtype=torch.float64, device=self.device)
+        self.in_dim = self.hidden = 0
+        self.packed = None
+        if predictor is not None:
+            self.set_predictor(predictor)
+
+    def set_predictor(self, predictor) -> None:
+        """predictor: a MinimalQualityPredictor (or anything with weights_numpy / input_dim / hidden_dim)."""
+        self.in_dim, self.hidden = predictor.input_dim, predictor.hidden_dim
+        self.packed = K.pack_mlp_weights(*predictor.weights_numpy(), device=self.device)
+
+    def update_lambda(self, lam: float) -> None:
+        self.lam = float(lam)
+
+    def verify(self, logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
+               out: Optional[K.VerifyResult] = None) -> K.VerifyResult:
+        return K.verify_accept(logits, tok, lp_draft, u, self.ws, out)
+
+    def step(self, logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
+             feat: Optional[torch.Tensor] = None, stage_idx: int = 0, out: Optional[K.VerifyResult] = None) -> StepResult:
+        """One verify + stop decision for the whole batch: two launches, nothing synchronises."""
+        v = self.verify(logits, tok, lp_draft, u, out)
+        s = None
+        if self.packed is not None and feat is not None:
+            s = K.predictor_stop(feat, self.packed, self.in_dim, self.hidden, stage_idx=stage_idx, L=self.L,
+                                 lp=v.lp_target, stats_col=self.stats_col, risk_adjustment=self.risk, n_obs=self.n_obs,
+                                 alpha=self.alpha, beta=self.beta, p_hist=self.p_hist[: tok.shape[0]], Cc=self.costs,
+                                 lam=self.lam, prefix_rule=self.prefix)
+        return StepResult(v, s)
+
+
+# ------------------------------------------------------------------------------------ plumbing
+def _sample(logits: torch.Tensor, temperature: float, gen: torch.Generator):
+    """logits [B,V] -> (tok [B] int64, log q(tok) [B] f32) under softmax(logits / T)."""
+    lp = torch.log_softmax(logits.float() / temperature, dim=-1)
+    tok = torch.multinomial(lp.exp(), 1, generator=gen)[:, 0]
+    return tok, lp.gather(1, tok[:, None])[:, 0]
+
+
+@dataclass
+class GenerationTrace:
+    tokens: torch.Tensor            # [B, T] committed tokens (prompt excluded)
+    steps: int
+    verified_tokens: int            # sum over steps and sequences of n_acc + 1
+    accept_masks: List[torch.Tensor]
+    step_inputs: List[dict]         # per step: logits/tok/lp_d/u as given to the verifier (for parity tests)
+    stop_flags: List[Optional[torch.Tensor]]
+
+
+@torch.no_grad()
+def speculative_generate(draft, target, prompt_ids: torch.Tensor, max_new_tokens: int, verifier: SpeculativeVerifier,
+                         *, temperature: float = 1.0, seed: int = 0, feat: Optional[torch.Tensor] = None,
+                         keep_inputs: bool = False) -> GenerationTrace:
+    """Drive two SyntheticLMs through draft/verify/accept/stop steps.  prompt_ids: [B, P] int64 on the GPU."""
+    dev = prompt_ids.device
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    B, Kd = prompt_ids.shape[0], verifier.Kd
+    draft.reset()
+    target.reset()
+    seq = prompt_ids
+    d_logits = draft(seq)[:, -1]                    # next-token logits after the prompt
+    t_last = target(seq)[:, -1]                     # target's next-token logits for the first position
+    out_tokens: List[torch.Tensor] = []
+    masks, inputs, stops = [], [], []
+    steps = verified = produced = 0
+    while produced < max_new_tokens:
+        base = seq.shape[1]
+        toks, lps, dls, dl = [], [], [], d_logits
+        for k in range(Kd):                         # draft K tokens autoregressively
+            t, lp = _sample(dl, temperature, gen)
+            toks.append(t)
+            lps.append(lp)
+            dls.append(dl)                          # kept for the residual distribution at a rejection
+            if k + 1 < Kd:
+                dl = draft(t[:, None])[:, -1]
+        tok = torch.stack(toks, 1)
+        lp_d = torch.stack(lps, 1).contiguous()
+        t_new = target(tok)                         # [B, K, V]: row k scores the token AFTER draft token k
+        # logits that score draft position k: k = 0 -> t_last, k > 0 -> t_new[:, k-1]
+        score = torch.cat([t_last[:, None], t_new[:, :-1]], dim=1).contiguous()
+        if temperature != 1.0:
+            score = (score.float() / temperature).to(score.dtype)
+        u = torch.rand((B, Kd), generator=gen, device=dev)
+        res = verifier.step(score, tok.to(torch.int32).contiguous(), lp_d, u, feat)
+        n_acc = res.verify.n_acc.to(torch.int64)
+        m = int(n_acc.min().item()) + 1             # lock-step commit length (keeps one KV length per model)
+        commit = tok[:, :m].clone()
+        # token m-1: the accepted draft token where n_acc >= m, else a sample from the residual
+        # max(0, p_t - p_d) at that position (standard speculative sampling)
+        need = n_acc < m
+        pos_logits = score[:, m - 1].float() if m - 1 < Kd else None
+        if m - 1 == Kd:                             # every sequence accepted all K: bonus token from the target
+            bonus, _ = _sample(t_new[:, -1], temperature, gen)
+            commit = torch.cat([tok, bonus[:, None]], 1)
+        elif need.any():
+            p_t = torch.softmax(pos_logits, -1)
+            p_d = torch.softmax(dls[m - 1].float() / temperature, -1)
+            resid = (p_t - p_d).clamp_min(0)
+            resid = torch.where(resid.sum(-1, keepdim=True) > 0, resid, p_t)
+            rs = torch.multinomial(resid / resid.sum(-1, keepdim=True), 1, generator=gen)[:, 0]
+            commit[:, m - 1] = torch.where(need, rs, commit[:, m - 1])
+        masks.append(res.verify.accept.clone())
+        stops.append(None if res.stop is None or res.stop.stop is None else res.stop.stop.clone())
+        if keep_inputs:
+            inputs.append(dict(logits=score.clone(), tok=tok.to(torch.int32).clone(), lp_d=lp_d.clone(), u=u.clone()))
+        verified += int(n_acc.sum().item()) + B
+        out_tokens.append(commit)
+        produced += commit.shape[1]
+        steps += 1
+        # roll both KV caches back to the committed prefix and feed the committed tokens not yet cached
+        seq = torch.cat([seq, commit], 1)
+        # position of the last committed token differs per sequence (accepted draft vs resample): drop it too
+        keep = base + commit.shape[1] - 1
+        draft.truncate(min(draft.cached_len, keep))
+        target.truncate(min(target.cached_len, keep))
+        d_logits = draft(seq[:, draft.cached_len:])[:, -1]
+        t_last = target(seq[:, target.cached_len:])[:, -1]
+    return GenerationTrace(torch.cat(out_tokens, 1)[:, :max_new_tokens], steps, verified, masks, inputs, stops)

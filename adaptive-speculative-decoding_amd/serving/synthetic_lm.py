@@ -1,0 +1,167 @@
+"""Synthetic random-weight Qwen2.5-shape language models -- PLUMBING for the token-level loop.
+
+The reference delegates model execution to vLLM / transformers (third party, parity
+unpinned) and fetches checkpoints by name, which is impossible offline.  To feed the verify kernel
+real `[B, K, V]` target logits this module builds the same ARCHITECTURE with locally initialised
+random weights: RMSNorm, grouped-query attention with rotary embeddings, SwiGLU MLP, untied
+lm_head.  Plain PyTorch-ROCm modules (rocBLAS / hipBLASLt GEMMs, SDPA); nothing here is a
+hand-written kernel and nothing here is measured by bench.py's headline number.
+
+Shapes (hidden, layers, heads, kv_heads, intermediate) follow the Qwen2.5 model cards; vocab is
+152064 for all of them.  `tiny(...)` is BASELINE configs[0]: 2 layers, hidden 128, vocab 1000.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclass
+class LMShape:
+    name: str
+    hidden: int
+    layers: int
+    heads: int
+    kv_heads: int
+    intermediate: int
+    vocab: int = 152064
+    rope_theta: float = 1.0e6
+    rms_eps: float = 1e-6
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    def param_count(self) -> int:
+        h, kv = self.hidden, self.kv_heads * self.head_dim
+        per_layer = h * h * 2 + h * kv * 2 + 3 * h * self.intermediate + 2 * h
+        return self.layers * per_layer + 2 * self.vocab * h + h
+
+
+QWEN25_SHAPES = {
+    "7b": LMShape("qwen2.5-7b", 3584, 28, 28, 4, 18944),
+    "14b": LMShape("qwen2.5-14b", 5120, 48, 40, 8, 13824),
+    "32b": LMShape("qwen2.5-32b", 5120, 64, 40, 8, 27648),
+    "72b": LMShape("qwen2.5-72b", 8192, 80, 64, 8, 29568),
+}
+
+
+def tiny(vocab: int = 1000, hidden: int = 128, layers: int = 2, heads: int = 4, kv_heads: int = 2) -> LMShape:
+    return LMShape("tiny", hidden, layers, heads, kv_heads, hidden * 3, vocab, rope_theta=10000.0)
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.eps = eps
+
+    def forward(self, x):
+        v = x.float()
+        v = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + self.eps)
+        return (v * self.weight.float()).to(x.dtype)
+
+
+def _rope(x: torch.Tensor, pos: torch.Tensor, theta: float) -> torch.Tensor:
+    """x: [B, H, T, D]; pos: [T] absolute positions."""
+    d = x.shape[-1]
+    inv = 1.0 / (theta ** (torch.arange(0, d, 2, device=x.device, dtype=torch.float32) / d))
+    ang = pos.float()[:, None] * inv[None, :]
+    cos, sin = ang.cos()[None, None], ang.sin()[None, None]
+    x1, x2 = x.float()[..., : d // 2], x.float()[..., d // 2:]
+    return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1).to(x.dtype)
+
+
+class Block(nn.Module):
+    def __init__(self, s: LMShape):
+        super().__init__()
+        self.s = s
+        kv = s.kv_heads * s.head_dim
+        self.ln1, self.ln2 = RMSNorm(s.hidden, s.rms_eps), RMSNorm(s.hidden, s.rms_eps)
+        self.q = nn.Linear(s.hidden, s.hidden, bias=True)
+        self.k = nn.Linear(s.hidden, kv, bias=True)
+        self.v = nn.Linear(s.hidden, kv, bias=True)
+        self.o = nn.Linear(s.hidden, s.hidden, bias=False)
+        self.gate = nn.Linear(s.hidden, s.intermediate, bias=False)
+        self.up = nn.Linear(s.hidden, s.intermediate, bias=False)
+        self.down = nn.Linear(s.intermediate, s.hidden, bias=False)
+
+    def forward(self, x, pos, cache: Optional[Tuple[torch.Tensor, torch.Tensor]]):
+        s = self.s
+        B, T, _ = x.shape
+        h = self.ln1(x)
+        q = self.q(h).view(B, T, s.heads, s.head_dim).transpose(1, 2)
+        k = self.k(h).view(B, T, s.kv_heads, s.head_dim).transpose(1, 2)
+        v = self.v(h).view(B, T, s.kv_heads, s.head_dim).transpose(1, 2)
+        q, k = _rope(q, pos, s.rope_theta), _rope(k, pos, s.rope_theta)
+        if cache is not None:
+            k = torch.cat([cache[0], k], dim=2)
+            v = torch.cat([cache[1], v], dim=2)
+        new_cache = (k, v)
+        rep = s.heads // s.kv_heads
+        kk = k.repeat_interleave(rep, dim=1) if rep > 1 else k
+        vv = v.repeat_interleave(rep, dim=1) if rep > 1 else v
+        S = kk.shape[2]
+        # causal mask for T new queries sitting at the END of S keys
+        mask = torch.ones(T, S, dtype=torch.bool, device=x.device).tril(diagonal=S - T)
+        a = F.scaled_dot_product_attention(q, kk, vv, attn_mask=mask)
+        x = x + self.o(a.transpose(1, 2).reshape(B, T, s.hidden))
+        h = self.ln2(x)
+        return x + self.down(F.silu(self.gate(h)) * self.up(h)), new_cache
+
+
+class SyntheticLM(nn.Module):
+    """Decoder-only LM with a KV cache that can be rolled back (`truncate`) after a rejection."""
+
+    def __init__(self, shape: LMShape, dtype: torch.dtype = torch.bfloat16, device=None, seed: int = 0,
+                 logit_scale: float = 1.0):
+        super().__init__()
+        self.shape = shape
+        self.logit_scale = logit_scale
+        g = torch.Generator().manual_seed(seed)
+        self.embed = nn.Embedding(shape.vocab, shape.hidden)
+        self.blocks = nn.ModuleList([Block(shape) for _ in range(shape.layers)])
+        self.norm = RMSNorm(shape.hidden, shape.rms_eps)
+        self.lm_head = nn.Linear(shape.hidden, shape.vocab, bias=False)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if p.dim() >= 2:                       # matrices ~ N(0, 1/fan_in); norms stay 1, biases 0
+                    p.copy_(torch.randn(p.shape, generator=g) * (1.0 / math.sqrt(p.shape[-1])))
+                elif name.endswith(".bias"):
+                    p.zero_()
+        self.to(device=device, dtype=dtype)
+        self.eval()
+        self._cache: List[Optional[Tuple[torch.Tensor, torch.Tensor]]] = [None] * shape.layers
+        self._len = 0
+
+    # -- cache management
+    def reset(self):
+        self._cache = [None] * self.shape.layers
+        self._len = 0
+
+    @property
+    def cached_len(self) -> int:
+        return self._len
+
+    def truncate(self, length: int):
+        """Keep the first `length` positions of the KV cache (KV rollback after a rejected suffix)."""
+        if length >= self._len:
+            return
+        self._cache = [None if c is None else (c[0][:, :, :length], c[1][:, :, :length]) for c in self._cache]
+        self._len = length
+
+    @torch.no_grad()
+    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+        """ids: [B, T] NEW tokens (positions cached_len ... cached_len+T-1) -> logits [B, T, V]."""
+        B, T = ids.shape
+        pos = torch.arange(self._len, self._len + T, device=ids.device)
+        x = self.embed(ids)
+        for i, blk in enumerate(self.blocks):
+            x, self._cache[i] = blk(x, pos, self._cache[i])
+        self._len += T
+        return self.lm_head(self.norm(x)) * self.logit_scale

@@ -47,3 +47,50 @@ class OracleBackend:
         B, K, V = store.shape
         r = O.verify_accept(store.reshape(B * K, V), dt, tok, lp_draft, u, B, K, V)
         return dict(lp_t=r["lp_t"], accept=r["accept"], n_acc=r["n_acc"], bits=r["bits"])
+
+
+class OracleOps:
+    """`ops` object for asd_amd.distributed on CPU tensors (gloo tests): same protocol as HipOps,
+    arithmetic by the oracle.  msg = (m2, s, g) float64 with sum_v exp(x) = s * 2^m2."""
+
+    @staticmethod
+    def _store(logits):
+        import torch
+        if logits.dtype == torch.bfloat16:
+            return logits.contiguous().view(torch.int16).numpy().view(np.uint16), O.DT_BF16
+        if logits.dtype == torch.float16:
+            return logits.contiguous().view(torch.int16).numpy().view(np.uint16), O.DT_F16
+        return logits.float().contiguous().numpy(), O.DT_F32
+
+    def verify_accept(self, logits, tok, lp_d, u):
+        import torch
+        store, dt = self._store(logits)
+        B, K, V = store.shape
+        r = O.verify_accept(store.reshape(B * K, V), dt, tok.numpy(), lp_d.numpy(), u.numpy(), B, K, V)
+        return (torch.from_numpy(r["lp_t"]), torch.from_numpy(r["accept"]), torch.from_numpy(r["n_acc"]),
+                torch.from_numpy(r["bits"].view(np.int64)))
+
+    def lse_partial(self, logits_shard, tok, v_offset):
+        import torch
+        store, dt = self._store(logits_shard)
+        B, K, V = store.shape
+        msg = O.lse_partial(store.reshape(B * K, V), dt, tok.numpy(), B, K, V, v_offset)
+        msg[..., 0] /= np.log(2.0)
+        return torch.from_numpy(msg)
+
+    def accept_from_partials(self, msg_all, lp_d, u):
+        import torch
+        m = msg_all.numpy().astype(np.float64)
+        R, B, K, _ = m.shape
+        with np.errstate(all="ignore"):
+            M = m[..., 0].max(axis=0)
+            s = (m[..., 1] * np.exp2(m[..., 0] - M[None])).sum(axis=0)
+            lse = np.log(2.0) * (M + np.log2(s))
+            g = m[..., 2].max(axis=0)
+            lp = g - lse
+            uu = u.numpy().astype(np.float64)
+            lu = np.where(uu > 0, np.log(np.where(uu > 0, uu, 1.0)), -np.inf)
+            acc = (lu <= lp - lp_d.numpy().astype(np.float64)).astype(np.uint8)
+        n_acc = np.array([int(np.argmin(np.append(a, 0))) for a in acc], dtype=np.int32)
+        bits = np.array([sum(int(a[k]) << k for k in range(K)) for a in acc], dtype=np.int64)
+        return torch.from_numpy(lp.astype(np.float32)), torch.from_numpy(acc), torch.from_numpy(n_acc), torch.from_numpy(bits)
