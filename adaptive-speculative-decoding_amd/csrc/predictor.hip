@@ -197,6 +197,33 @@ struct FusedParams {
     float* score; int32_t* k_star; uint8_t* stop; uint8_t* thr_stop; double* stats;
 };
 
+// lane-0 tail of the fused epilogue: Bayes adjustment, history update, DP rule, theta test
+__device__ __forceinline__ void decide_and_store(const FusedParams& p, int b, float sc) {
+    if (p.score) p.score[b] = sc;
+    // pipeline.py:225-238: prob = predictor.predict(...); prob = bayesian_adjustment(prob, n_obs, a, b)
+    double prob = static_cast<double>(sc);
+    if (p.risk) prob = bayes_adjust1(prob, p.n_obs, p.alpha, p.beta);
+    if (p.p_hist) {
+        double* ph = p.p_hist + static_cast<int64_t>(b) * p.L;
+        ph[p.stage_idx] = prob;
+        if (p.k_star || p.stop) {
+            const int n_dp = p.prefix ? p.stage_idx + 1 : p.L;       // pipeline.py:248-256 uses the prefix
+            double pp[ASD_MAX_STAGES], cc[ASD_MAX_STAGES], J[ASD_MAX_STAGES + 1];
+#pragma unroll
+            for (int i = 0; i < ASD_MAX_STAGES; ++i) {
+                if (i < n_dp) { pp[i] = (i == p.stage_idx) ? prob : ph[i]; cc[i] = p.C[i]; }
+            }
+            const int ks = optimal_stopping1(pp, cc, p.lam, n_dp, 0, 1.0, 1.0, J);
+            if (p.k_star) p.k_star[b] = ks;
+            if (p.stop) p.stop[b] = (ks == p.stage_idx) ? 1 : 0;     // pipeline.py:259
+        }
+    }
+    if (p.theta && p.thr_stop) {
+        const double q = static_cast<double>(sc);                    // minimal_adaptive_decoder.py:159-161
+        p.thr_stop[b] = (q >= p.theta[p.stage_idx] || p.stage_idx == p.L - 1) ? 1 : 0;
+    }
+}
+
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_predictor_stop(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -239,34 +266,71 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_predictor_stop(const Fu
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const float sc = wave_mlp(w, xs, p.in_dim, p.hidden, lane);
-        if (lane == 0) {
-            if (p.score) p.score[b] = sc;
-            // pipeline.py:225-238: prob = predictor.predict(...); prob = bayesian_adjustment(prob, n_obs, a, b)
-            double prob = static_cast<double>(sc);
-            if (p.risk) prob = bayes_adjust1(prob, p.n_obs, p.alpha, p.beta);
-            if (p.p_hist) {
-                double* ph = p.p_hist + static_cast<int64_t>(b) * p.L;
-                ph[p.stage_idx] = prob;
-                if (p.k_star || p.stop) {
-                    const int n_dp = p.prefix ? p.stage_idx + 1 : p.L;       // pipeline.py:248-256 uses the prefix
-                    double pp[ASD_MAX_STAGES], cc[ASD_MAX_STAGES], J[ASD_MAX_STAGES + 1];
-#pragma unroll
-                    for (int i = 0; i < ASD_MAX_STAGES; ++i) {
-                        if (i < n_dp) { pp[i] = (i == p.stage_idx) ? prob : ph[i]; cc[i] = p.C[i]; }
-                    }
-                    const int ks = optimal_stopping1(pp, cc, p.lam, n_dp, 0, 1.0, 1.0, J);
-                    if (p.k_star) p.k_star[b] = ks;
-                    if (p.stop) p.stop[b] = (ks == p.stage_idx) ? 1 : 0;     // pipeline.py:259
-                }
-            }
-            if (p.theta && p.thr_stop) {
-                const double q = static_cast<double>(sc);                    // minimal_adaptive_decoder.py:159-161
-                p.thr_stop[b] = (q >= p.theta[p.stage_idx] || p.stage_idx == p.L - 1) ? 1 : 0;
-            }
-        }
+        if (lane == 0) decide_and_store(p, b, sc);
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+// Latency form for the reference's predictor (64 -> 32 -> 1) and K <= 64: one wave per sequence,
+// every global load issued up front, the first layer split over the two half-waves with its
+// weights in registers (32 per lane).  This is what a decode step calls (B = tens of sequences):
+// the work is a few thousand flops, so the only thing that matters is the length of the
+// dependency chain.
+__global__ __launch_bounds__(64) void k_predictor_stop_w64x32(const FusedParams p) {
+    __shared__ double dvals[3 * 64];
+    __shared__ __attribute__((aligned(16))) float xs[64];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const bool want_stats = p.lp && (p.stats_col >= 0 || p.stats);
+    // ---- phase 0: loads
+    int n = p.K;
+    if (want_stats && p.n_valid) n = p.n_valid[b];
+    float lpv = 0.0f;
+    if (want_stats && lane < p.K) lpv = p.lp[static_cast<int64_t>(b) * p.ld_lp + lane];
+    float xv = p.feat[static_cast<int64_t>(b) * p.ldf + lane];
+    const int j = lane & 31, half = lane >> 5;
+    float w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = p.packed[(half * 32 + i) * 32 + j];
+    const float b1 = p.packed[64 * 32 + j];
+    const float w2 = p.packed[64 * 32 + 32 + j];
+    const float b2 = p.packed[64 * 32 + 64];
+    // ---- phase 1: statistics of the log-probs
+    n = n < 0 ? 0 : (n > p.K ? p.K : n);
+    double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (want_stats) {
+        if (lane < n) dvals[lane] = static_cast<double>(lpv);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_logprob_stats(dvals, dvals + 64, dvals + 128, n, lane, st);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) st[i] = __shfl(st[i], 0, 64);
+        if (p.stats && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
+        }
+        const int si = lane - p.stats_col;
+        if (p.stats_col >= 0 && si >= 0 && si < 5)
+            xv = static_cast<float>(si == 0 ? st[0] : si == 1 ? st[1] : si == 2 ? st[2] : si == 3 ? st[3] : st[4]);
+    }
+    xs[lane] = xv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- phase 2: MLP
+    float h = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) h = fmaf(w[i], xs[half * 32 + i], h);
+    h += __shfl_xor(h, 32, 64);
+    h = fmaxf(h + b1, 0.0f);
+    float z = half == 0 ? w2 * h : 0.0f;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) z += __shfl_xor(z, off, 64);
+    const float sc = 1.0f / (1.0f + expf(-(z + b2)));
+    if (lane == 0) decide_and_store(p, b, sc);
+}
+
 
 inline bool mlp_dims_ok(int in_dim, int hidden) {
     return in_dim >= 1 && hidden >= 1 && in_dim <= ASD_MAX_MLP_DIM && hidden <= ASD_MAX_MLP_DIM;
@@ -354,6 +418,10 @@ ASD_EXPORT int asd_predictor_stop(const float* lp, int64_t ld_lp, const int32_t*
     int blocks = (B + kWavesPerBlock - 1) / kWavesPerBlock;
     const int cap = current_device_cus() * 8;
     if (blocks > cap) blocks = cap;
+    if (in_dim == 64 && hidden == 32 && K <= 64 && B <= 8192) {
+        hipLaunchKernelGGL(k_predictor_stop_w64x32, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), p);
+        return launch_status();
+    }
     hipLaunchKernelGGL(k_predictor_stop, dim3(blocks), dim3(64 * kWavesPerBlock), lds, static_cast<hipStream_t>(stream), p);
     return launch_status();
 }

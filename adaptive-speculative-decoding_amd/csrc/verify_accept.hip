@@ -7,8 +7,8 @@
 // of THREADS lanes reduces one slice to a pair (m2, s) with   sum_v exp(x_v) = s * 2^m2
 // (log2 domain: the per-element work is one FMA + one v_exp_f32, and the pair stays exactly
 // consistent whatever rounding m2 itself carries).  Each lane keeps a running (m2, s) over its
-// 16-byte vectors (online softmax, one rescale per vector), lanes are folded with a fixed
-// xor-butterfly, waves through LDS.
+// 16-byte vectors (online softmax, one rescale per vector); lanes are folded max-first with DPP
+// row shifts (one rescale per lane), waves through LDS and the same fold on wave 0.
 //
 // Streaming loop.  16-byte buffer loads through a per-slice descriptor whose num_records is the
 // slice end: lanes past the end are dropped by the range check (no memory access), so every batch
@@ -43,6 +43,19 @@
 // reference symbol; it is specified in include/asd_hip.h and DESIGN.md.
 
 #include "common.hpp"
+
+#ifdef ASD_STAMP
+// Diagnostic build only (tools/stamp_verify.py builds a separate .so with -DASD_STAMP): per-workgroup
+// phase stamps of the 100 MHz realtime counter, written to a buffer nothing else reads.
+__device__ unsigned long long* g_asd_stamps = nullptr;
+#define ASD_STAMP_AT(slot)                                                                       \
+    do {                                                                                         \
+        if (threadIdx.x == 0 && g_asd_stamps)                                                    \
+            g_asd_stamps[static_cast<size_t>(blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define ASD_STAMP_AT(slot) do { } while (0)
+#endif
 
 namespace asd {
 namespace {
@@ -85,6 +98,39 @@ __device__ __forceinline__ void ms_merge(float& m2, float& s, float m2b, float s
     const float ea = fast_exp2(m2 - M);
     const float eb = fast_exp2(m2b - M);
     s = fmaf(s, ea, sb * eb);
+    m2 = M;
+}
+
+// ---- wave64 reductions on DPP (row_shr 1,2,4,8 then row_bcast 15 / 31: the GFX9 sequence; the
+// total lands in lane 63 and is broadcast with v_readlane).  `__shfl_xor` lowers to ds_bpermute
+// (an LDS round trip per step); a 6-step butterfly of (m2, s) pairs cost ~2 us on the kernel's
+// tail (gpurun stamps, profiles/r01_stamps_*.log), this costs a few hundred cycles.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_move<0x111, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x112, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x114, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x118, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x142, 0xa>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x143, 0xc>(-INFINITY, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_move<0x111, 0xf>(0.0f, v);
+    v += dpp_move<0x112, 0xf>(0.0f, v);
+    v += dpp_move<0x114, 0xf>(0.0f, v);
+    v += dpp_move<0x118, 0xf>(0.0f, v);
+    v += dpp_move<0x142, 0xa>(0.0f, v);
+    v += dpp_move<0x143, 0xc>(0.0f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// all 64 lanes' (m2, s) -> one pair, valid (uniform) in every lane: max first, ONE rescale per lane
+__device__ __forceinline__ void wave_merge(float& m2, float& s) {
+    const float M = wave_max(m2);
+    s = wave_sum(s * fast_exp2(m2 - M));
     m2 = M;
 }
 
@@ -200,12 +246,14 @@ __device__ __forceinline__ double log2_split(float x) {
 // The sums are f64 (they mirror the oracle's structure); the two logarithms are split into an
 // exact exponent and a v_log_f32 of the mantissa, which keeps their absolute error ~1e-7 without
 // a software f64 log on the kernel's tail.
-__device__ __forceinline__ bool finish_row(float m2, float s, float x_tok, float lp_d, float u,
+__device__ __forceinline__ double log_u(float u) {
+    return kLn2d * log2_split(u);  // u == 0 -> -inf (accepts), u < 0 -> NaN (rejects)
+}
+__device__ __forceinline__ bool finish_row(float m2, float s, float x_tok, float lp_d, double lu,
                                            float& lp_out) {
     const double lse = kLn2d * (static_cast<double>(m2) + log2_split(s));
     const double lp = static_cast<double>(x_tok) - lse;
     lp_out = static_cast<float>(lp);
-    const double lu = kLn2d * log2_split(u);  // u == 0 -> -inf (accepts), u < 0 -> NaN (rejects)
     return lu <= lp - static_cast<double>(lp_d);
 }
 
@@ -244,6 +292,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     __shared__ float red_s[kWaves];
     __shared__ uint64_t stage[kMaxStage];
 
+    ASD_STAMP_AT(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -267,6 +316,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     // the row's own scalars, fetched by lane 0 under the stream (one workgroup per row only)
     const bool own_row = (S == 1) && (p.mode == 1 || p.K <= kFastMaxK);
     float x_tok = -INFINITY, lpd = 0.0f, uu = 1.0f;
+    double lu_row = 0.0;
     int64_t t_tok = -1;
     if (own_row && tid == 0) {
         t_tok = static_cast<int64_t>(p.tok[row]) - p.v_offset;
@@ -292,6 +342,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) ra[j] = load16<NT>(rsrc, off + static_cast<uint32_t>(j) * THREADS * 16u);
         if (own_row && tid == 0 && t_tok >= 0 && t_tok < p.V) x_tok = E::scalar(rowp, t_tok);
+        if (own_row && tid == 0 && p.mode == 0) lu_row = log_u(uu);   // off the tail: runs under the stream
         uint32_t bi = 0;
         while (true) {  // ping-pong: ra holds batch bi, rb receives batch bi+1 (and vice versa)
             if (bi + 1 < n_all) {
@@ -301,6 +352,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
             }
             if (bi < n_full) consume<DT, UNROLL, THREADS, false>(ra, off, end, m2, s);
             else consume<DT, UNROLL, THREADS, true>(ra, off, end, m2, s);
+            if (bi == 0) ASD_STAMP_AT(1);
             off += kBatchBytes;
             if (++bi >= n_all) break;
             if (bi + 1 < n_all) {
@@ -313,27 +365,24 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
             off += kBatchBytes;
             if (++bi >= n_all) break;
         }
-    } else if (own_row && tid == 0 && t_tok >= 0 && t_tok < p.V) {
-        x_tok = E::scalar(rowp, t_tok);
+    } else if (own_row && tid == 0) {
+        if (t_tok >= 0 && t_tok < p.V) x_tok = E::scalar(rowp, t_tok);
+        if (p.mode == 0) lu_row = log_u(uu);
     }
 
-    // lanes -> wave (fixed xor butterfly), waves -> workgroup (LDS)
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const float om = __shfl_xor(m2, o, 64);
-        const float os = __shfl_xor(s, o, 64);
-        ms_merge(m2, s, om, os);
-    }
+    ASD_STAMP_AT(2);
+    // lanes -> wave (DPP max, one rescale, DPP sum), waves -> workgroup (LDS, then the same on wave 0)
+    wave_merge(m2, s);
     if (kWaves > 1) {
         if (lane == 0) { red_m[wave] = m2; red_s[wave] = s; }
         __syncthreads();
         if (wave != 0) return;
-        m2 = red_m[0];
-        s = red_s[0];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) ms_merge(m2, s, red_m[w], red_s[w]);
+        m2 = lane < kWaves ? red_m[lane] : kSentinel;
+        s = lane < kWaves ? red_s[lane] : 0.0f;
+        wave_merge(m2, s);
     }
     // only wave 0 is left here
+    ASD_STAMP_AT(3);
 
     if (own_row) {
         // ---- one workgroup per row: finish the row here ---------------------------------------
@@ -345,12 +394,13 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
             return;
         }
         float lp;
-        const bool flag = finish_row(m2, s, x_tok, lpd, uu, lp);
+        const bool flag = finish_row(m2, s, x_tok, lpd, lu_row, lp);
         p.lp_t[row] = lp;
         p.accept[row] = flag ? 1 : 0;
         // ballot by atomic: count in the high word, this row's flag at bit k of the low word
         uint64_t* word = reinterpret_cast<uint64_t*>(p.tickets + static_cast<int64_t>(b) * kTicketStride + 2);
         const uint64_t mine = (1ull << 32) | (static_cast<uint64_t>(flag ? 1u : 0u) << k);
+        ASD_STAMP_AT(4);
         const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (static_cast<uint32_t>(old >> 32) == static_cast<uint32_t>(p.K - 1)) {
             const uint32_t mask = static_cast<uint32_t>(old | mine);
@@ -360,6 +410,10 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
             if (p.bits) p.bits[b] = mask;
             __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#ifdef ASD_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g_asd_stamps) g_asd_stamps[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime() + (old & 0);
+#endif
         return;
     }
 
@@ -412,7 +466,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     bool flag = false;
     if (lane < p.K) {
         float lp;
-        flag = finish_row(fm, fs, x_tok, lpd, uu, lp);
+        flag = finish_row(fm, fs, x_tok, lpd, log_u(uu), lp);
         p.lp_t[frow] = lp;
         p.accept[frow] = flag ? 1 : 0;
     }
@@ -436,7 +490,7 @@ __global__ __launch_bounds__(64) void k_accept_from_partials(const float* msg_al
             g = (gr != gr) ? gr : fmaxf(g, gr);  // a NaN logit must not be dropped by max
         }
         float lp;
-        flag = finish_row(m2, s, g, lp_d[row], u[row], lp);
+        flag = finish_row(m2, s, g, lp_d[row], log_u(u[row]), lp);
         lp_t[row] = lp;
         accept[row] = flag ? 1 : 0;
     }
@@ -551,6 +605,12 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
 }  // namespace asd
 
 using namespace asd;
+
+#ifdef ASD_STAMP
+ASD_EXPORT int asd_debug_set_stamp_buffer(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_asd_stamps), &buf, sizeof(buf)) == hipSuccess ? ASD_OK : ASD_ERR_HIP;
+}
+#endif
 
 ASD_EXPORT size_t asd_verify_accept_workspace_bytes(int B, int K, int V, int dtype) {
     (void)V;

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a verify launch spend its time?  Builds a SEPARATE library with -DASD_STAMP
+(gpurun_out/libasd_hip_stamp.so; the shipped library never contains stamps), runs a workload and
+prints, relative to the earliest workgroup start, the distribution of
+  t0 start | t1 first batch consumed | t2 stream end | t3 workgroup reduced | t4 before ticket | t5 done.
+Stamp = s_memrealtime (100 MHz => 10 ns ticks).
+
+    python tools/stamp_verify.py [c3|c2|c5] [splits,threads,unroll,nt]
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from bench import WORKLOADS, build_inputs  # noqa: E402
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+    geom = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 0, 0, -1]
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    lib_path = os.path.join(out, "libasd_hip_stamp.so")
+    csrc = os.path.join(ROOT, "adaptive-speculative-decoding_amd", "csrc")
+    subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-DASD_STAMP",
+                           f"-I{ROOT}/include", f"-I{csrc}", os.path.join(csrc, "verify_accept.hip"),
+                           os.path.join(csrc, "api.hip"), "-o", lib_path])
+    lib = C.CDLL(lib_path)
+    from asd_amd import kernels as K
+    B, Kk, V, _ = WORKLOADS[wl]
+    dev = torch.device("cuda", 0)
+    nbuf = max(3, math.ceil(640e6 / (B * Kk * V * 2)))
+    ws, bufs = build_inputs(torch, K, B, Kk, V, nbuf, dev, 1234)
+    nblk = B * Kk * 64
+    stamps = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
+    lib.asd_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+    assert lib.asd_debug_set_stamp_buffer(stamps.data_ptr()) == 0
+    fn = lib.asd_verify_accept_tuned
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int,
+                   C.c_int, C.c_int]
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for it in range(12):
+        buf = bufs[it % nbuf]
+        o = buf["out"]
+        stamps.zero_()
+        torch.cuda.synchronize()
+        rc = fn(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(), buf["u"].data_ptr(), B, Kk,
+                V, o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(), o.accept_bits.data_ptr(),
+                ws.buf.data_ptr(), ws.bytes, st, *geom)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        s = stamps.cpu().numpy()
+        live = s[:, 0] > 0
+        s = s[live].astype(np.float64)
+        t0 = s[:, 0].min()
+        rel = (s[:, :6] - t0) / 100.0      # us
+        if it >= 2:
+            res.append(rel)
+    rel = np.concatenate(res)
+    names = ["start", "first batch consumed", "stream end", "wg reduced", "before ticket", "done"]
+    print(f"workload {wl}, geometry {geom}, {len(res)} launches, {rel.shape[0] // len(res)} workgroups each; us from first start")
+    for i, n in enumerate(names):
+        col = rel[:, i]
+        col = col[col >= 0]
+        if col.size == 0:
+            continue
+        print(f"  {n:22s} min {col.min():7.2f}  p50 {np.median(col):7.2f}  p90 {np.percentile(col, 90):7.2f}  max {col.max():7.2f}")
+    per = rel[:, 2] - rel[:, 1]
+    print(f"  stream phase (t2-t1)   p50 {np.median(per):7.2f}  max {per.max():7.2f}")
+    print(f"  ramp (t1-t0)           p50 {np.median(rel[:, 1] - rel[:, 0]):7.2f}  max {(rel[:, 1] - rel[:, 0]).max():7.2f}")
+    ok = rel[:, 5] > 0
+    print(f"  tail (t5-t2)           p50 {np.median((rel[:, 5] - rel[:, 2])[ok]):7.2f}  max {(rel[:, 5] - rel[:, 2])[ok].max():7.2f}")
+
+
+if __name__ == "__main__":
+    main()
