@@ -11,9 +11,10 @@
 // row shifts (one rescale per lane), waves through LDS and the same fold on wave 0.
 //
 // Streaming loop.  16-byte buffer loads through a per-slice descriptor whose num_records is the
-// slice end: lanes past the end are dropped by the range check (no memory access), so every batch
-// is issued unconditionally and the loop is software-pipelined (batch i+1 in flight while batch i
-// is reduced; UNROLL..2*UNROLL KiB-loads outstanding per wave).
+// slice end: lanes past the end are dropped by the range check (no memory access), so loads are
+// issued unconditionally.  The slice is cut into UNROLL-KiB tiles that waves claim from an LDS
+// counter (two tiles in flight per wave); each tile is reduced to its own (m2, s) slot and the
+// slots are folded in tile order, so the result is bitwise independent of the claim order.
 //
 // One workgroup per row (S == 1, K <= 32; the regime rows >= CUs).  The row's workgroup finishes
 // its own row: lane 0 prefetches tok / lp_d / u and the drafted token's logit while the row
@@ -268,14 +269,14 @@ __device__ __forceinline__ void finish_sequence(bool flag, int lane, int K, int 
     }
 }
 
-template <int DT, int UNROLL, int THREADS, bool CHECK>
+template <int DT, int UNROLL, bool CHECK>
 __device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, uint32_t end, float& m2, float& s) {
     using E = Elem<DT>;
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) {
         u32x4 v = r[j];
         if (CHECK) {  // past the slice end the range check returned zeros: make them -inf
-            const bool ok = off + static_cast<uint32_t>(j) * THREADS * 16u < end;
+            const bool ok = off + static_cast<uint32_t>(j) * 1024u < end;
             const u32x4 neg = {E::kNegInfWord, E::kNegInfWord, E::kNegInfWord, E::kNegInfWord};
             v = ok ? v : neg;
         }
@@ -287,12 +288,14 @@ template <int DT, int THREADS, int UNROLL, bool NT>
 __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     using E = Elem<DT>;
     constexpr int kWaves = THREADS / 64;
-    constexpr uint32_t kBatchBytes = static_cast<uint32_t>(UNROLL) * THREADS * 16u;
-    __shared__ float red_m[kWaves];
-    __shared__ float red_s[kWaves];
-    __shared__ uint64_t stage[kMaxStage];
+    __shared__ uint32_t next_tile;
+    __shared__ uint64_t stage[kMaxStage];   // tile slots while streaming, granule staging for the finisher
 
     ASD_STAMP_AT(0);
+#ifdef ASD_STAMP
+    if (threadIdx.x == 0 && g_asd_stamps)   // HW_REG_XCC_ID (id 20), all 32 bits
+        g_asd_stamps[static_cast<size_t>(blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -323,64 +326,92 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
         if (p.mode == 0) { lpd = p.lp_d[row]; uu = p.u[row]; }
     }
 
-    float m2 = kSentinel, s = 0.0f;
-
-    // unaligned head / ragged tail (<= 7 elements each), folded into the first / last slice
-    if (split == 0 && tid < head) accum_scalar(E::scalar(rowp, tid), m2, s);
-    if (split == S - 1 && tid < tail)
-        accum_scalar(E::scalar(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + tid), m2, s);
-
-    if (v1 > v0) {
-        // descriptor over [body + v0*16, body + v1*16): block-uniform, so it lives in SGPRs
-        const uint32_t end = static_cast<uint32_t>(v1 - v0) * 16u;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(body) + static_cast<int64_t>(v0) * 16, 0, static_cast<int>(end), 0x00020000);
-        const uint32_t n_full = end / kBatchBytes;                       // batches with every lane in range
-        const uint32_t n_all = (end + kBatchBytes - 1) / kBatchBytes;
-        uint32_t off = static_cast<uint32_t>(tid) * 16u;
-        u32x4 ra[UNROLL], rb[UNROLL];
+    // ---- streaming: waves claim UNROLL-KiB tiles from an LDS counter ---------------------------
+    // Static striding lets the oldest wave group run ahead (age-priority arbitration: measured
+    // stream ends 11.9 / 12.6 / 13.4 / 14.6 us for the four groups of a 1024-lane workgroup), so
+    // the CU's memory pipe idles while the youngest waves drain alone.  With dynamic claims all
+    // waves end within one tile of each other.  Determinism is kept by construction: every tile
+    // is reduced to its OWN (m2, s) slot, and slots are combined in tile order afterwards, so the
+    // result does not depend on which wave processed which tile.
+    constexpr uint32_t kTileBytes = static_cast<uint32_t>(UNROLL) * 1024u;
+    const uint32_t end = v1 > v0 ? static_cast<uint32_t>(v1 - v0) * 16u : 0u;
+    const uint32_t n_tiles = (end + kTileBytes - 1) / kTileBytes;   // launcher: n_tiles + 1 <= kMaxStage
+    const uint32_t n_full = end / kTileBytes;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(body) + static_cast<int64_t>(v0) * 16, 0, static_cast<int>(end), 0x00020000);
+    const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
+    if (tid == 0) next_tile = 2u * kWaves;
+    uint32_t ta = static_cast<uint32_t>(wave), tb = static_cast<uint32_t>(wave) + kWaves;
+    u32x4 ra[UNROLL], rb[UNROLL];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) ra[j] = load16<NT>(rsrc, off + static_cast<uint32_t>(j) * THREADS * 16u);
-        if (own_row && tid == 0 && t_tok >= 0 && t_tok < p.V) x_tok = E::scalar(rowp, t_tok);
-        if (own_row && tid == 0 && p.mode == 0) lu_row = log_u(uu);   // off the tail: runs under the stream
-        uint32_t bi = 0;
-        while (true) {  // ping-pong: ra holds batch bi, rb receives batch bi+1 (and vice versa)
-            if (bi + 1 < n_all) {
+    for (int j = 0; j < UNROLL; ++j) ra[j] = load16<NT>(rsrc, ta * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
 #pragma unroll
-                for (int j = 0; j < UNROLL; ++j)
-                    rb[j] = load16<NT>(rsrc, off + kBatchBytes + static_cast<uint32_t>(j) * THREADS * 16u);
-            }
-            if (bi < n_full) consume<DT, UNROLL, THREADS, false>(ra, off, end, m2, s);
-            else consume<DT, UNROLL, THREADS, true>(ra, off, end, m2, s);
-            if (bi == 0) ASD_STAMP_AT(1);
-            off += kBatchBytes;
-            if (++bi >= n_all) break;
-            if (bi + 1 < n_all) {
-#pragma unroll
-                for (int j = 0; j < UNROLL; ++j)
-                    ra[j] = load16<NT>(rsrc, off + kBatchBytes + static_cast<uint32_t>(j) * THREADS * 16u);
-            }
-            if (bi < n_full) consume<DT, UNROLL, THREADS, false>(rb, off, end, m2, s);
-            else consume<DT, UNROLL, THREADS, true>(rb, off, end, m2, s);
-            off += kBatchBytes;
-            if (++bi >= n_all) break;
-        }
-    } else if (own_row && tid == 0) {
+    for (int j = 0; j < UNROLL; ++j) rb[j] = load16<NT>(rsrc, tb * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
+    if (own_row && tid == 0) {   // off the tail: the gather and log(u) run under the stream
         if (t_tok >= 0 && t_tok < p.V) x_tok = E::scalar(rowp, t_tok);
         if (p.mode == 0) lu_row = log_u(uu);
     }
+    if (wave == 0) {
+        // unaligned head / ragged tail (<= 7 elements each) of the first / last slice: slot n_tiles
+        float hm = kSentinel, hs = 0.0f;
+        if (split == 0 && lane < head) accum_scalar(E::scalar(rowp, lane), hm, hs);
+        if (split == S - 1 && lane >= 32 && lane - 32 < tail)
+            accum_scalar(E::scalar(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + (lane - 32)), hm, hs);
+        wave_merge(hm, hs);
+        if (lane == 0) stage[n_tiles] = (static_cast<uint64_t>(__float_as_uint(hs)) << 32) | __float_as_uint(hm);
+    }
+    __syncthreads();   // next_tile is visible; the first two tiles of every wave are already in flight
+
+#define ASD_CLAIM(dst)                                                                                   \
+    do {                                                                                                 \
+        uint32_t c_ = 0;                                                                                 \
+        if (lane == 0) c_ = __hip_atomic_fetch_add(&next_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        dst = __builtin_amdgcn_readfirstlane(c_);                                                        \
+    } while (0)
+#define ASD_REDUCE_TILE(reg, t)                                                                          \
+    do {                                                                                                 \
+        float tm_ = kSentinel, ts_ = 0.0f;                                                               \
+        if ((t) < n_full) consume<DT, UNROLL, false>(reg, (t) * kTileBytes + lane_off, end, tm_, ts_);   \
+        else consume<DT, UNROLL, true>(reg, (t) * kTileBytes + lane_off, end, tm_, ts_);                 \
+        wave_merge(tm_, ts_);                                                                            \
+        if (lane == 0) stage[(t)] = (static_cast<uint64_t>(__float_as_uint(ts_)) << 32) | __float_as_uint(tm_); \
+    } while (0)
+
+    bool first = true;
+    while (ta < n_tiles) {   // claims are monotonic per wave: ta < tb at the top of every iteration
+        uint32_t tn;
+        ASD_CLAIM(tn);
+        ASD_REDUCE_TILE(ra, ta);
+        if (first) { ASD_STAMP_AT(1); first = false; }
+        ta = tn;
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) ra[j] = load16<NT>(rsrc, ta * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
+        if (tb >= n_tiles) break;
+        ASD_CLAIM(tn);
+        ASD_REDUCE_TILE(rb, tb);
+        tb = tn;
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) rb[j] = load16<NT>(rsrc, tb * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
+    }
+#undef ASD_CLAIM
+#undef ASD_REDUCE_TILE
 
     ASD_STAMP_AT(2);
-    // lanes -> wave (DPP max, one rescale, DPP sum), waves -> workgroup (LDS, then the same on wave 0)
-    wave_merge(m2, s);
-    if (kWaves > 1) {
-        if (lane == 0) { red_m[wave] = m2; red_s[wave] = s; }
-        __syncthreads();
-        if (wave != 0) return;
-        m2 = lane < kWaves ? red_m[lane] : kSentinel;
-        s = lane < kWaves ? red_s[lane] : 0.0f;
-        wave_merge(m2, s);
+#ifdef ASD_STAMP
+    if (lane == 0 && g_asd_stamps)   // per-wave stream end, after the per-workgroup records
+        g_asd_stamps[static_cast<size_t>(gridDim.x) * 8 + static_cast<size_t>(blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
+#endif
+    // tile slots -> slice: wave 0 folds slots lane, lane+64, ... in order, then across lanes
+    __syncthreads();
+    if (wave != 0) return;
+    float m2 = kSentinel, s = 0.0f;
+    for (uint32_t t = static_cast<uint32_t>(lane); t <= n_tiles; t += 64) {
+        const uint64_t g = stage[t];
+        ms_merge(m2, s, __uint_as_float(static_cast<uint32_t>(g)), __uint_as_float(static_cast<uint32_t>(g >> 32)));
     }
+    wave_merge(m2, s);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the slots are dead; `stage` is reused below
+    __builtin_amdgcn_wave_barrier();
     // only wave 0 is left here
     ASD_STAMP_AT(3);
 
@@ -507,22 +538,21 @@ struct Geometry {
     int splits, threads, unroll, nt;
 };
 
-// Launch geometry (numbers: profiles/r01_sweep_*.json, MI355X, 256 CUs).
-//   rows >= CUs : one workgroup per row, no split.  1024 lanes x 2-deep batches when every CU gets
-//                 exactly one row-sized workgroup, 512 lanes x 4 when rows queue up behind each other
-//                 (B=32: 16.8 us, B=128: 51.7 us = 6.0 TB/s).
-//   rows <  CUs : split rows until ~2 workgroups of 256 lanes per CU exist (B=8: S=8, 9.6 us); a slice
-//                 is never cut below one full batch per workgroup.
+// Launch geometry (numbers: profiles/r01_sweep_*.json, MI355X, 256 CUs, dynamic-tile kernel).
+//   rows >= CUs : one workgroup per row, no split.  1024 lanes x 2-KiB tiles when every CU gets exactly
+//                 one row-sized workgroup (B=32: 16.2 us), 512 lanes x 4-KiB tiles when rows queue up
+//                 behind each other (B=128: 49.1 us = 6.34 TB/s).
+//   rows <  CUs : split rows until ~one 512-lane workgroup per CU exists (B=8: S=4, 8.6 us); a slice is
+//                 never cut below one tile per wave.
 Geometry choose_geometry(int R, int K, int V, int dtype, int cus) {
     Geometry g{1, 1024, 2, 1};
     if (R > cus) { g.threads = 512; g.unroll = 4; }
     if (R >= cus) return g;
-    g.threads = 256;
+    g.threads = 512;
     g.unroll = 2;
-    const int64_t row_vecs = static_cast<int64_t>(V) * dtype_size(dtype) / 16;
-    const int64_t batch = static_cast<int64_t>(g.threads) * g.unroll;
-    int64_t want = (static_cast<int64_t>(cus) * 2 + R - 1) / (R > 0 ? R : 1);
-    int64_t cap = row_vecs / batch;
+    const int64_t row_bytes = static_cast<int64_t>(V) * dtype_size(dtype);
+    int64_t want = (static_cast<int64_t>(cus) + R - 1) / (R > 0 ? R : 1);
+    int64_t cap = row_bytes / (static_cast<int64_t>(g.threads / 64) * g.unroll * 1024);
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
     const int smax = max_splits_for(K);
@@ -574,11 +604,21 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     if (R > INT32_MAX) return ASD_ERR_UNSUPPORTED;
 
     const Geometry h = choose_geometry(static_cast<int>(R), p.K, p.V, dtype, current_device_cus());
+    const bool auto_unroll = g.unroll <= 0, auto_splits = g.splits <= 0;
     if (g.splits <= 0) g.splits = h.splits;
     if (g.threads <= 0) g.threads = h.threads;
     if (g.unroll <= 0) g.unroll = h.unroll;
     if (g.nt < 0) g.nt = h.nt;
     if (g.splits > max_splits_for(p.K)) return ASD_ERR_UNSUPPORTED;
+    // every tile of a slice owns an LDS slot: tiles + 1 <= kMaxStage (a 152064-wide bf16 row is 149 tiles)
+    for (;;) {
+        const int64_t slice_bytes = (static_cast<int64_t>(p.V) * esz + g.splits - 1) / g.splits + 16;
+        const int64_t tiles = (slice_bytes + g.unroll * 1024 - 1) / (g.unroll * 1024);
+        if (tiles + 1 <= kMaxStage) break;
+        if (auto_unroll && g.unroll < 8) { g.unroll *= 2; continue; }
+        if (auto_splits && g.splits * 2 <= max_splits_for(p.K)) { g.splits *= 2; continue; }
+        return ASD_ERR_UNSUPPORTED;
+    }
 
     const size_t ticket_bytes = round_up(static_cast<size_t>(p.B) * kTicketStride * sizeof(uint32_t), 256);
     const size_t region_bytes = round_up(static_cast<size_t>(p.K) * g.splits * sizeof(uint64_t), 256);

@@ -38,7 +38,7 @@ def main():
     nbuf = max(3, math.ceil(640e6 / (B * Kk * V * 2)))
     ws, bufs = build_inputs(torch, K, B, Kk, V, nbuf, dev, 1234)
     nblk = B * Kk * 64
-    stamps = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
+    stamps = torch.zeros((nblk * 24,), dtype=torch.int64, device=dev)
     lib.asd_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     assert lib.asd_debug_set_stamp_buffer(stamps.data_ptr()) == 0
     fn = lib.asd_verify_accept_tuned
@@ -46,7 +46,7 @@ def main():
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int,
                    C.c_int, C.c_int]
     st = torch.cuda.current_stream().cuda_stream
-    res = []
+    res, xcc, waves = [], [], []
     for it in range(12):
         buf = bufs[it % nbuf]
         o = buf["out"]
@@ -57,13 +57,18 @@ def main():
                 ws.buf.data_ptr(), ws.bytes, st, *geom)
         assert rc == 0, rc
         torch.cuda.synchronize()
-        s = stamps.cpu().numpy()
+        raw = stamps.cpu().numpy()
+        grid = B * Kk * (geom[0] if geom[0] > 0 else 1)   # default geometry at rows >= CUs: one workgroup per row
+        s = raw[: grid * 8].reshape(grid, 8)
+        wv = raw[grid * 8: grid * 8 + grid * 16].reshape(grid, 16).astype(np.float64)
         live = s[:, 0] > 0
         s = s[live].astype(np.float64)
         t0 = s[:, 0].min()
         rel = (s[:, :6] - t0) / 100.0      # us
         if it >= 2:
             res.append(rel)
+            xcc.append(s[:, 6].astype(int))
+            waves.append((wv - t0) / 100.0)
     rel = np.concatenate(res)
     names = ["start", "first batch consumed", "stream end", "wg reduced", "before ticket", "done"]
     print(f"workload {wl}, geometry {geom}, {len(res)} launches, {rel.shape[0] // len(res)} workgroups each; us from first start")
@@ -80,5 +85,21 @@ def main():
     print(f"  tail (t5-t2)           p50 {np.median((rel[:, 5] - rel[:, 2])[ok]):7.2f}  max {(rel[:, 5] - rel[:, 2])[ok].max():7.2f}")
 
 
+    w = np.concatenate(waves)
+    w = w[:, (w > 0).all(axis=0)]
+    print("  per-wave stream end by wave index (p50 over workgroups):")
+    print("    " + " ".join(f"{np.median(w[:, i]):5.2f}" for i in range(w.shape[1])))
+    print(f"    slowest-wave p50 {np.median(w.max(axis=1)):5.2f}  mean-wave p50 {np.median(w.mean(axis=1)):5.2f}  fastest-wave p50 {np.median(w.min(axis=1)):5.2f}")
+    return rel, np.concatenate(xcc)
+
+
+def per_xcd(rel, xcc):
+    print("  per-XCD stream end (t2) p50 / max, and workgroups seen:")
+    for x in sorted(set(xcc.tolist())):
+        col = rel[xcc == x, 2]
+        print(f"    xcd {x}: p50 {np.median(col):6.2f}  max {col.max():6.2f}  n {col.size}")
+
+
 if __name__ == "__main__":
-    main()
+    r, x = main()
+    per_xcd(r, x)
