@@ -3,6 +3,13 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5]
 
+Launch modes (--mode): `graph` (default) captures runs of steps in one hipGraph on one stream;
+`eager` is plain stream-ordered launches (within 2 % of graph here: the loop is GPU-bound);
+`overlap` forks each step's epilogue to a side stream inside the graph -- measured 29 us/step vs
+21 us: cross-queue dependencies cost more than the 5 us epilogue they hide, so it is not the
+default.  All modes execute exactly the same kernels on the same buffers and time exactly --steps
+steps.
+
 A step = ONE pass of the hot path over one batch of synthetic target logits already resident in
 HBM:  asd_verify_accept (gather + log-sum-exp + acceptance test over [B,K,V] bf16)  followed by
 asd_predictor_stop (log-prob statistics -> 64-d features -> 64x32x1 predictor -> Bayes -> DP stop
@@ -169,6 +176,12 @@ def main():
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--verify-only", action="store_true", help="skip the predictor/stop epilogue launch")
+    ap.add_argument("--mode", choices=["graph", "eager", "overlap"], default="graph",
+                    help="graph: runs of steps captured in one hipGraph on one stream (default; falls back to eager if "
+                         "capture fails); eager: plain launches; overlap: epilogue forked to a side stream inside the "
+                         "graph (measured SLOWER on this stack: cross-queue edges cost more than the 5 us they hide)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo + ASD_BENCH_ONE_DEVICE=1 rehearses the N>1 control flow with every rank on cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -184,12 +197,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("ASD_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0                                   # rehearsal on a 1-GPU box (use with --dist-backend gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1
+    red_dev = device if args.dist_backend == "nccl" else torch.device("cpu")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     B, K, V, desc = WORKLOADS[args.workload]
     bytes_per_launch = algorithmic_bytes(B, K, V)
@@ -202,7 +221,6 @@ def main():
     Cc = torch.tensor(STAGE_COSTS, dtype=torch.float64, device=device)
     p_hist = torch.ones((B, N_STAGES), dtype=torch.float64, device=device)
     lib = Kmod._lib()
-    stream = torch.cuda.current_stream().cuda_stream
     geom = (args.splits, args.threads, args.unroll, args.nontemporal)
 
     # pre-bound launch closures: no allocation, no Python-side tensor work inside the timed loop
@@ -211,21 +229,23 @@ def main():
     stop = torch.empty((B,), dtype=torch.uint8, device=device)
     n_valid = torch.full((B,), K, dtype=torch.int32, device=device)
 
-    def verify(buf):
+    def verify(buf, stream=None):
         o = buf["out"]
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         rc = lib.asd_verify_accept_tuned(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(),
                                          buf["u"].data_ptr(), B, K, V, o.lp_target.data_ptr(), o.accept.data_ptr(),
                                          o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes,
-                                         stream, *geom)
+                                         st, *geom)
         if rc:
             raise RuntimeError(f"asd_verify_accept_tuned rc={rc}")
 
-    def epilogue(buf):
+    def epilogue(buf, stream=None):
         o = buf["out"]
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         rc = lib.asd_predictor_stop(o.lp_target.data_ptr(), K, n_valid.data_ptr(), K, feat.data_ptr(), 64, 5,
                                     packed.data_ptr(), 64, 32, 1, 100, 1.0, 1.0, p_hist.data_ptr(), Cc.data_ptr(), 1.0,
                                     N_STAGES, 0, 0, None, B, score.data_ptr(), k_star.data_ptr(), stop.data_ptr(),
-                                    None, None, stream)
+                                    None, None, st)
         if rc:
             raise RuntimeError(f"asd_predictor_stop rc={rc}")
 
@@ -239,20 +259,68 @@ def main():
         if distributed:
             dist.barrier()
 
+    def capture(first, count, overlap):
+        """`count` consecutive steps starting at step index `first` as ONE hipGraph.  overlap: the epilogue
+        of step i is forked to a side stream (edge: after verify i) and joined at the end of the graph, so
+        it runs under verify i+1.  The buffers a step touches are distinct for nbuf consecutive steps."""
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=device)
+        with torch.cuda.graph(g):
+            main = torch.cuda.current_stream()
+            for j in range(count):
+                buf = bufs[(first + j) % nbuf]
+                verify(buf, main.cuda_stream)
+                if args.verify_only:
+                    continue
+                if overlap:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    epilogue(buf, side.cuda_stream)
+                else:
+                    epilogue(buf, main.cuda_stream)
+            if overlap and not args.verify_only:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                main.wait_event(ev)
+        return g
+
     for i in range(args.warmup):
         step(i)
+    # steps per graph: a divisor of --steps (<= 2*nbuf) so that replays cover EXACTLY --steps steps;
+    # graph step j always runs buffer (warmup + j) % nbuf, so the token accounting below holds for every mode
+    G = 1
+    if args.mode != "eager":
+        for cand in range(min(args.steps, 2 * nbuf), 0, -1):
+            if args.steps % cand == 0:
+                G = cand
+                break
+    graph = None
+    if args.mode != "eager" and G > 1:
+        torch.cuda.synchronize()
+        try:
+            graph = capture(args.warmup, G, overlap=(args.mode == "overlap"))
+            graph.replay()                              # one untimed replay: graph upload
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001  (e.g. capture refused under a profiler): same kernels, eager
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graph, G = None, 1
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    if graph is not None:
+        for _ in range(args.steps // G):
+            graph.replay()
+    else:
+        for i in range(args.steps):
+            step(args.warmup + i)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
 
     # verified tokens: outputs per buffer are deterministic, so count them after the timed region
     per_buf = [int(b["out"].n_acc.sum().item()) + B for b in bufs]
-    tokens = sum(per_buf[(args.warmup + i) % nbuf] for i in range(args.steps))
+    tokens = sum(per_buf[(args.warmup + (i % G)) % nbuf] for i in range(args.steps))
     # kernel-only duration: back-to-back verify launches bracketed by two events, best-of-3 + mean
     reps = max(args.steps, 100)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -269,13 +337,13 @@ def main():
     kern_min_ms = min(runs)
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tk = torch.tensor([tokens], dtype=torch.float64, device=device)
+        tk = torch.tensor([tokens], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tk, op=dist.ReduceOp.SUM)
         tokens = int(tk.item())
-        km = torch.tensor([kern_mean_ms], dtype=torch.float64, device=device)
+        km = torch.tensor([kern_mean_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
         kern_mean_ms = float(km.item())
 
@@ -299,6 +367,7 @@ def main():
                                    + ("" if args.verify_only else " + asd_predictor_stop (stats->MLP->Bayes->DP)"),
                        "batch_per_gpu": B, "draft_len": K, "vocab": V, "accumulate": "f32 (epilogue f64)",
                        "rotating_buffers": nbuf, "buffer_MB": round(B * K * V * 2 / 1e6, 2),
+                       "launch_mode": args.mode if graph is not None else "eager", "steps_per_graph": G,
                        "tiers": "7B-draft / 32B / 72B-target shapes (vocab 152064); logits synthetic",
                        "parallelism": f"batch-parallel replicas x{world}" if world > 1 else "single GPU",
                        "geometry": {"splits": args.splits, "threads": args.threads, "unroll": args.unroll,

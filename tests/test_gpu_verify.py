@@ -35,9 +35,10 @@ def test_ragged_and_misaligned_rows(dtype, V, ld):
     assert_verify_matches(run_gpu_verify(case), case["ref"])
 
 
-@pytest.mark.parametrize("B", [8, 32])
+@pytest.mark.parametrize("B", [8, 32, 128])
 def test_full_size_bf16(B):
-    """BASELINE configs[1] (B=8) and the headline config (B=32), draft_len 8, vocab 152064."""
+    """BASELINE configs[1] (B=8), the headline config (B=32) and the per-node batch of configs[4]
+    (B=128), draft_len 8, vocab 152064."""
     case = make_verify_case(B, 8, 152064, O.DT_BF16, seed=1234, n_threads=16)
     got = run_gpu_verify(case)
     assert_verify_matches(got, case["ref"])
@@ -237,3 +238,53 @@ def test_vocab_sharded_path_matches_single_launch(K_):
         got = dict(lp_t=out.lp_target.cpu().numpy(), accept=out.accept.cpu().numpy(), n_acc=out.n_acc.cpu().numpy(),
                    bits=out.accept_bits.cpu().numpy().view(np.uint64))
         assert_verify_matches(got, case["ref"])
+
+
+@pytest.mark.parametrize("B,K,V", [(8, 40, 5000), (5, 64, 3001), (300, 1, 4099), (33, 8, 7777)])
+def test_row_parallel_paths_beyond_the_ballot_word(B, K, V):
+    """rows >= CUs with K > 32 (ticket path at S = 1), K = 1 (per-token log-prob shape of A6), and a
+    batch that is not a multiple of anything."""
+    case = make_verify_case(B, K, V, O.DT_BF16, seed=B * K)
+    assert_verify_matches(run_gpu_verify(case), case["ref"])
+
+
+def test_lse_partial_row_parallel_form(K_):
+    """asd_lse_partial where rows >= CUs (one workgroup per row writes its triple directly)."""
+    import torch
+    B, K, V = 40, 8, 24000
+    case = make_verify_case(B, K, V, O.DT_BF16, seed=77)
+    lg = to_device_logits(case["logits"], case["dtype"]).view(B, K, V)
+    tok = torch.from_numpy(case["tok"]).cuda()
+    ws = K_.VerifyWorkspace(B, K, V)
+    halves = [(0, 11000), (11000, V)]
+    msgs = [K_.lse_partial(lg[:, :, a:b], tok, a, ws) for a, b in halves]
+    out = K_.accept_from_partials(torch.stack(msgs).contiguous(), torch.from_numpy(case["lp_d"]).cuda(),
+                                  torch.from_numpy(case["u"]).cuda())
+    torch.cuda.synchronize()
+    got = dict(lp_t=out.lp_target.cpu().numpy(), accept=out.accept.cpu().numpy(), n_acc=out.n_acc.cpu().numpy(),
+               bits=out.accept_bits.cpu().numpy().view(np.uint64))
+    assert_verify_matches(got, case["ref"])
+
+
+def test_concurrent_calls_on_two_streams_need_two_workspaces(K_):
+    """Two verify calls in flight at once (different streams), each with its own workspace."""
+    import torch
+    c1 = make_verify_case(32, 8, 30000, O.DT_BF16, seed=101)
+    c2 = make_verify_case(32, 8, 30000, O.DT_BF16, seed=202)
+    args = []
+    for c in (c1, c2):
+        args.append((to_device_logits(c["logits"], c["dtype"]).view(32, 8, 30000), torch.from_numpy(c["tok"]).cuda(),
+                     torch.from_numpy(c["lp_d"]).cuda(), torch.from_numpy(c["u"]).cuda(),
+                     K_.VerifyWorkspace(32, 8, 30000)))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for rep in range(20):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                outs[i].append(K_.verify_accept(*args[i][:4], args[i][4]))
+    torch.cuda.synchronize()
+    for i, c in enumerate((c1, c2)):
+        for r in outs[i]:
+            assert np.array_equal(r.accept.cpu().numpy(), c["ref"]["accept"])
+            assert np.array_equal(r.n_acc.cpu().numpy(), c["ref"]["n_acc"])
