@@ -186,6 +186,47 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_mlp_predict(const float
     }
 }
 
+// Throughput form for the reference's predictor (64 -> 32 -> 1) at large batch: ONE LANE PER ROW.
+// The row lives in 64 VGPRs, the 32 hidden accumulators in 32 more, and the weights never touch
+// a vector register or LDS: W1T[i][0..32) is wave-uniform, so it arrives through the scalar cache
+// (s_load) and feeds v_fmac as an SGPR operand.  2112 FMAs per row => VALU-bound at ~28 us per
+// million rows on 256 CUs, i.e. at the HBM rate of reading the 260 B rows (the wave-per-row
+// latency form above spends its time in LDS round trips: 811 us per million rows, measured).
+__global__ __launch_bounds__(256) void k_mlp_rows_64x32(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ packed, int B,
+                                                        float* __restrict__ score) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= B) return;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const float* xr = x + row * ldx;
+    float xv[64];
+    if ((reinterpret_cast<uintptr_t>(xr) & 15u) == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * i);
+            xv[4 * i] = v[0]; xv[4 * i + 1] = v[1]; xv[4 * i + 2] = v[2]; xv[4 * i + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) xv[i] = xr[i];
+    }
+    const float* b1 = packed + 64 * 32;
+    const float* w2 = b1 + 32;
+    float h[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) h[j] = b1[j];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) h[j] = fmaf(packed[i * 32 + j], xv[i], h[j]);   // packed[...] is uniform: SGPR
+    }
+    float z = w2[32];                                        // b2
+#pragma unroll
+    for (int j = 0; j < 32; ++j) z = fmaf(w2[j], fmaxf(h[j], 0.0f), z);
+    score[row] = 1.0f / (1.0f + expf(-z));
+}
+
+
 // ---- fused epilogue: one wave per sequence ------------------------------------------------
 struct FusedParams {
     const float* lp; int64_t ld_lp; const int32_t* n_valid; int K;
@@ -378,6 +419,11 @@ ASD_EXPORT int asd_mlp_predict(const float* x, int64_t ldx, const float* packed_
     if (!mlp_dims_ok(in_dim, hidden)) return ASD_ERR_UNSUPPORTED;
     if (B == 0) return ASD_OK;
     if (!x || !packed_w || !score || ldx < in_dim) return ASD_ERR_INVALID_ARG;
+    if (in_dim == 64 && hidden == 32 && B >= 4096) {   // throughput form: one lane per row, weights on the scalar path
+        hipLaunchKernelGGL(k_mlp_rows_64x32, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx,
+                           packed_w, B, score);
+        return launch_status();
+    }
     const size_t wbytes = asd_mlp_packed_floats(in_dim, hidden) * sizeof(float);
     const int use_lds = wbytes <= kWeightLdsLimit;
     const size_t lds = sizeof(float) * kWavesPerBlock * in_dim + (use_lds ? wbytes : 0);

@@ -182,8 +182,10 @@ def pack_mlp_weights(w1, b1, w2, b2, device=None) -> torch.Tensor:
 def mlp_predict(x: torch.Tensor, packed_w: torch.Tensor, in_dim: int, hidden: int) -> torch.Tensor:
     """A8 (eval mode): x [B,in_dim] f32 -> score [B] f32."""
     Bv = x.shape[0]
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or (Bv and x.stride(1) != 1):
+        raise ValueError("x must be a [B, in_dim] float32 CUDA tensor with unit stride along in_dim (rows may be strided)")
     out = torch.empty((Bv,), dtype=torch.float32, device=x.device)
-    rc = _lib().asd_mlp_predict(_dev(x, "x", torch.float32), x.stride(0) if Bv else in_dim,
+    rc = _lib().asd_mlp_predict(x.data_ptr(), x.stride(0) if Bv else in_dim,
                                 _dev(packed_w, "packed_w", torch.float32), Bv, in_dim, hidden, out.data_ptr(), _stream())
     B.check("asd_mlp_predict", rc)
     return out

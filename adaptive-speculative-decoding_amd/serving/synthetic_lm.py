@@ -56,9 +56,9 @@ def tiny(vocab: int = 1000, hidden: int = 128, layers: int = 2, heads: int = 4, 
 
 
 class RMSNorm(nn.Module):
-    def __init__(self, dim: int, eps: float):
+    def __init__(self, dim: int, eps: float, **kw):
         super().__init__()
-        self.weight = nn.Parameter(torch.ones(dim))
+        self.weight = nn.Parameter(torch.ones(dim, **kw))
         self.eps = eps
 
     def forward(self, x):
@@ -78,18 +78,18 @@ def _rope(x: torch.Tensor, pos: torch.Tensor, theta: float) -> torch.Tensor:
 
 
 class Block(nn.Module):
-    def __init__(self, s: LMShape):
+    def __init__(self, s: LMShape, **kw):
         super().__init__()
         self.s = s
         kv = s.kv_heads * s.head_dim
-        self.ln1, self.ln2 = RMSNorm(s.hidden, s.rms_eps), RMSNorm(s.hidden, s.rms_eps)
-        self.q = nn.Linear(s.hidden, s.hidden, bias=True)
-        self.k = nn.Linear(s.hidden, kv, bias=True)
-        self.v = nn.Linear(s.hidden, kv, bias=True)
-        self.o = nn.Linear(s.hidden, s.hidden, bias=False)
-        self.gate = nn.Linear(s.hidden, s.intermediate, bias=False)
-        self.up = nn.Linear(s.hidden, s.intermediate, bias=False)
-        self.down = nn.Linear(s.intermediate, s.hidden, bias=False)
+        self.ln1, self.ln2 = RMSNorm(s.hidden, s.rms_eps, **kw), RMSNorm(s.hidden, s.rms_eps, **kw)
+        self.q = nn.Linear(s.hidden, s.hidden, bias=True, **kw)
+        self.k = nn.Linear(s.hidden, kv, bias=True, **kw)
+        self.v = nn.Linear(s.hidden, kv, bias=True, **kw)
+        self.o = nn.Linear(s.hidden, s.hidden, bias=False, **kw)
+        self.gate = nn.Linear(s.hidden, s.intermediate, bias=False, **kw)
+        self.up = nn.Linear(s.hidden, s.intermediate, bias=False, **kw)
+        self.down = nn.Linear(s.intermediate, s.hidden, bias=False, **kw)
 
     def forward(self, x, pos, cache: Optional[Tuple[torch.Tensor, torch.Tensor]]):
         s = self.s
@@ -123,18 +123,25 @@ class SyntheticLM(nn.Module):
         super().__init__()
         self.shape = shape
         self.logit_scale = logit_scale
-        g = torch.Generator().manual_seed(seed)
-        self.embed = nn.Embedding(shape.vocab, shape.hidden)
-        self.blocks = nn.ModuleList([Block(shape) for _ in range(shape.layers)])
-        self.norm = RMSNorm(shape.hidden, shape.rms_eps)
-        self.lm_head = nn.Linear(shape.hidden, shape.vocab, bias=False)
+        # parameters are created and initialised directly on the target device in the target dtype:
+        # a 72B-shape model is 145 GB and must never pass through host memory
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        kw = dict(device="meta")
+        self.embed = nn.Embedding(shape.vocab, shape.hidden, **kw)
+        self.blocks = nn.ModuleList([Block(shape, **kw) for _ in range(shape.layers)])
+        self.norm = RMSNorm(shape.hidden, shape.rms_eps, **kw)
+        self.lm_head = nn.Linear(shape.hidden, shape.vocab, bias=False, **kw)
+        self.to_empty(device=dev)
+        self.to(dtype)
+        g = torch.Generator(device=dev).manual_seed(seed)
         with torch.no_grad():
             for name, p in self.named_parameters():
-                if p.dim() >= 2:                       # matrices ~ N(0, 1/fan_in); norms stay 1, biases 0
-                    p.copy_(torch.randn(p.shape, generator=g) * (1.0 / math.sqrt(p.shape[-1])))
+                if p.dim() >= 2:                       # matrices ~ N(0, 1/fan_in); norms 1, biases 0
+                    p.normal_(0.0, 1.0 / math.sqrt(p.shape[-1]), generator=g)
                 elif name.endswith(".bias"):
                     p.zero_()
-        self.to(device=device, dtype=dtype)
+                else:
+                    p.fill_(1.0)
         self.eval()
         self._cache: List[Optional[Tuple[torch.Tensor, torch.Tensor]]] = [None] * shape.layers
         self._len = 0

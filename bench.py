@@ -180,6 +180,9 @@ def main():
                     help="graph: runs of steps captured in one hipGraph on one stream (default; falls back to eager if "
                          "capture fails); eager: plain launches; overlap: epilogue forked to a side stream inside the "
                          "graph (measured SLOWER on this stack: cross-queue edges cost more than the 5 us they hide)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank verifies a full batch of the workload; strong: the workload's batch is "
+                         "split over the ranks (B/rank = B/world)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + ASD_BENCH_ONE_DEVICE=1 rehearses the N>1 control flow with every rank on cuda:0")
     args = ap.parse_args()
@@ -211,6 +214,10 @@ def main():
             dist.init_process_group("gloo")
 
     B, K, V, desc = WORKLOADS[args.workload]
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit(f"--scaling strong needs the batch ({B}) to divide by the ranks ({world})")
+        B //= world
     bytes_per_launch = algorithmic_bytes(B, K, V)
     nbuf = max(3, math.ceil(640e6 / (B * K * V * 2)))
     ws, bufs = build_inputs(torch, Kmod, B, K, V, nbuf, device, seed=1234 + rank)
@@ -359,7 +366,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
@@ -377,7 +384,7 @@ def main():
                          "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
                          "traffic_source": traffic_src,
                          "kernel": "asd::k_verify (verify_accept.hip)", "algorithmic_bytes": bytes_per_launch,
-                         "kernel_ms_mean": kern_mean_ms, "kernel_ms_best_run": kern_min_ms,
+                         "kernel_ms_mean": kern_mean_ms, "kernel_ms_best_run": kern_min_ms, "kernel_ms_runs": runs,
                          "timing": f"HIP events on the launch stream around 3 runs of {reps} back-to-back verify launches "
                                    "(rotating buffers) right after the timed region; includes inter-kernel gaps",
                          "note": "event PAIRS around single launches add 5-15 us each on this stack (measured in round 1) and are not used"},

@@ -44,6 +44,26 @@ def test_mlp_shapes_vs_oracle(K_, D, H, B):
     np.testing.assert_allclose(got, want, rtol=0, atol=SCORE_ATOL)
 
 
+def test_mlp_throughput_form_and_strided_rows(golden, K_):
+    """B >= 4096 takes the lane-per-row kernel (weights on the scalar path); rows may be strided and
+    need not be 16-byte aligned."""
+    import torch
+    g = golden.npz("predictor.npz")
+    packed = K_.pack_mlp_weights(g["w1"], g["b1"], g["w2"], g["b2"])
+    rng = np.random.default_rng(4)
+    for B in (4096, 4097, 50000):
+        big = rng.standard_normal((B, 67)).astype(np.float32)
+        xb = torch.from_numpy(big).cuda()
+        for view, ref in ((xb[:, :64], big[:, :64]), (xb[:, 1:65], big[:, 1:65]), (xb[:, 3:67].contiguous(), big[:, 3:67])):
+            got = K_.mlp_predict(view, packed, 64, 32).cpu().numpy()
+            want = O.mlp_predict(np.ascontiguousarray(ref), g["w1"], g["b1"], g["w2"][0], g["b2"])
+            np.testing.assert_allclose(got, want, rtol=0, atol=SCORE_ATOL)
+    small = K_.mlp_predict(torch.from_numpy(g["X"]).cuda(), packed, 64, 32).cpu().numpy()       # latency form
+    rep = K_.mlp_predict(torch.from_numpy(np.tile(g["X"], (20, 1))).cuda(), packed, 64, 32).cpu().numpy()  # 5120 rows
+    np.testing.assert_allclose(rep[:256], small, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rep[:256], g["scores"], rtol=0, atol=SCORE_ATOL)
+
+
 def test_logprob_stats_goldens_bit_exact(golden, K_):
     """A7 columns [5:10] of the reference's extract_features, float64, bit for bit."""
     g = golden.npz("features_a7.npz")

@@ -288,3 +288,25 @@ def test_concurrent_calls_on_two_streams_need_two_workspaces(K_):
         for r in outs[i]:
             assert np.array_equal(r.accept.cpu().numpy(), c["ref"]["accept"])
             assert np.array_equal(r.n_acc.cpu().numpy(), c["ref"]["n_acc"])
+
+
+def test_hipgraph_capture_and_replay(K_):
+    """The launcher does nothing a capture forbids and the self-resetting tickets survive replay."""
+    import torch
+    case = make_verify_case(32, 8, 20000, O.DT_BF16, seed=314)
+    lg = to_device_logits(case["logits"], case["dtype"]).view(32, 8, 20000)
+    tok, lp_d, u = (torch.from_numpy(case[k]).cuda() for k in ("tok", "lp_d", "u"))
+    ws = K_.VerifyWorkspace(32, 8, 20000)
+    out = K_.verify_accept(lg, tok, lp_d, u, ws)            # eager warm-up (also caches the CU count)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(3):
+            K_.verify_accept(lg, tok, lp_d, u, ws, out)
+    for _ in range(5):
+        out.accept.zero_()
+        out.n_acc.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.accept.cpu().numpy(), case["ref"]["accept"])
+        assert np.array_equal(out.n_acc.cpu().numpy(), case["ref"]["n_acc"])
