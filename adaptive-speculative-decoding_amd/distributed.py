@@ -138,3 +138,20 @@ class TierLink:
     def send_verdict(self, accept: torch.Tensor, n_acc: torch.Tensor) -> None:
         buf = torch.cat([accept.reshape(-1).to(torch.int32), n_acc.reshape(-1).to(torch.int32)]).contiguous()
         dist.send(buf, dst=self.draft_rank, group=self.group)
+
+    # generic small messages (committed tokens; ONE draft-logits row per sequence after a rejection)
+    def send_to_target(self, t: torch.Tensor) -> None:
+        dist.send(t.contiguous(), dst=self.target_rank, group=self.group)
+
+    def send_to_draft(self, t: torch.Tensor) -> None:
+        dist.send(t.contiguous(), dst=self.draft_rank, group=self.group)
+
+    def recv_from_draft(self, shape, dtype, device) -> torch.Tensor:
+        buf = torch.empty(shape, dtype=dtype, device=device)
+        dist.recv(buf, src=self.draft_rank, group=self.group)
+        return buf
+
+    def recv_from_target(self, shape, dtype, device) -> torch.Tensor:
+        buf = torch.empty(shape, dtype=dtype, device=device)
+        dist.recv(buf, src=self.target_rank, group=self.group)
+        return buf
