@@ -34,6 +34,9 @@ SIGNATURES = {
     "asd_verify_accept": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "asd_verify_accept_tuned": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                      _vp, _i, _i, _i, _i]),
+    "asd_verify_accept_fused": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
+                                     _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d, _i, _i, _i, _vp,
+                                     _vp, _vp, _vp, _vp, _vp, _vp]),
     "asd_lse_partial": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "asd_accept_from_partials": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),

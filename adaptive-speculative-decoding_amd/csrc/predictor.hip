@@ -10,9 +10,7 @@
 // MACs, far below one MFMA tile's worth of launch latency.  One wave per row, hidden units on
 // lanes, weights staged once per workgroup in LDS, f32 FMAs in registers.
 
-#include "decision_device.hpp"
-
-#include <math.h>
+#include "predictor_device.hpp"
 
 namespace asd {
 namespace {
@@ -21,98 +19,6 @@ constexpr int kStatsMaxK = 1024;     // values per sequence the stats path stage
 constexpr int kWavesPerBlock = 4;
 constexpr size_t kWeightLdsLimit = 32 * 1024;  // keep every launch under the 64 KiB default LDS window
 constexpr int kFusedMaxK = 128;                   // fused epilogue: the reference caps generations at 128 tokens
-
-// ---- numpy pairwise summation (numpy/_core/src/umath/loops_utils.h.src: pairwise_sum) -----
-// n < 8: sequential from 0; n <= 128: eight interleaved accumulators, fixed tree, sequential
-// tail; n > 128: split at (n/2 rounded down to a multiple of 8).  Recursion unrolled by depth
-// (kStatsMaxK = 128 * 2^3).
-__device__ double np_sum_leaf(const double* a, int n) {
-    if (n < 8) {
-        double res = 0.0;
-        for (int i = 0; i < n; ++i) res = res + a[i];
-        return res;
-    }
-    double r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = a[j];
-    int i = 8;
-    for (; i < n - (n % 8); i += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
-    }
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res = res + a[i];
-    return res;
-}
-__device__ __forceinline__ int np_split(int n) { int h = n / 2; return h - (h % 8); }
-__device__ double np_sum_d1(const double* a, int n) {
-    if (n <= 128) return np_sum_leaf(a, n);
-    const int h = np_split(n);
-    return np_sum_leaf(a, h) + np_sum_leaf(a + h, n - h);
-}
-__device__ double np_sum_d2(const double* a, int n) {
-    if (n <= 128) return np_sum_leaf(a, n);
-    const int h = np_split(n);
-    return np_sum_d1(a, h) + np_sum_d1(a + h, n - h);
-}
-__device__ double np_sum(const double* a, int n) {  // n <= 1024
-    if (n <= 128) return np_sum_leaf(a, n);
-    const int h = np_split(n);
-    return np_sum_d2(a, h) + np_sum_d2(a + h, n - h);
-}
-
-// numpy _lerp (numpy/lib/_function_base_impl.py)
-__device__ __forceinline__ double np_lerp(double a, double b, double t) {
-    const double d = b - a;
-    double r = a + d * t;
-    if (t >= 0.5) r = b - d * (1.0 - t);
-    if (d == 0.0) r = a;
-    return r;
-}
-
-// One wave computes the five statistics of vals[0..n) (f64, in LDS); `sorted` and `sq` are LDS
-// scratch of n doubles each.  Result valid in lane 0.
-__device__ void wave_logprob_stats(double* vals, double* sorted, double* sq, int n, int lane, double (&out)[5]) {
-    if (n <= 0) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) out[i] = 0.0;             // features.extend([0.0]*5) :174-175
-        return;
-    }
-    // rank sort (stable): every value lands at #{smaller} + #{equal and earlier}
-    for (int i = lane; i < n; i += 64) {
-        const double v = vals[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const double w = vals[j];
-            rank += (w < v) || (w == v && j < i);
-        }
-        sorted[rank] = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double mean = 0.0;
-    if (lane == 0) mean = np_sum(vals, n) / static_cast<double>(n);          // np.mean :168
-    mean = __shfl(mean, 0, 64);
-    for (int i = lane; i < n; i += 64) {
-        const double t = vals[i] - mean;
-        sq[i] = t * t;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0) {
-        const double var = np_sum(sq, n) / static_cast<double>(n);            // np.std :169 (population)
-        const double vi = static_cast<double>(n - 1) * 0.25;                  // np.percentile(.,25) :171
-        const int lo = static_cast<int>(floor(vi));
-        const int hi = lo + 1 < n ? lo + 1 : n - 1;
-        out[0] = mean;
-        out[1] = sqrt(var);
-        out[2] = sorted[0];                                                   // np.min :170
-        out[3] = np_lerp(sorted[lo], sorted[hi], vi - static_cast<double>(lo));
-        out[4] = (n & 1) ? sorted[n / 2] : (sorted[n / 2 - 1] + sorted[n / 2]) / 2.0;  // np.median :172
-    }
-}
 
 __global__ __launch_bounds__(64) void k_logprob_stats(const float* __restrict__ lp, int64_t ld,
                                                       const int32_t* __restrict__ n_valid, int B, int K,
@@ -227,44 +133,7 @@ __global__ __launch_bounds__(256) void k_mlp_rows_64x32(const float* __restrict_
 }
 
 
-// ---- fused epilogue: one wave per sequence ------------------------------------------------
-struct FusedParams {
-    const float* lp; int64_t ld_lp; const int32_t* n_valid; int K;
-    const float* feat; int64_t ldf; int stats_col;
-    const float* packed; int in_dim, hidden, use_lds;
-    int risk; double n_obs, alpha, beta;
-    double* p_hist; const double* C; double lam; int L, stage_idx, prefix;
-    const double* theta; int B;
-    float* score; int32_t* k_star; uint8_t* stop; uint8_t* thr_stop; double* stats;
-};
-
-// lane-0 tail of the fused epilogue: Bayes adjustment, history update, DP rule, theta test
-__device__ __forceinline__ void decide_and_store(const FusedParams& p, int b, float sc) {
-    if (p.score) p.score[b] = sc;
-    // pipeline.py:225-238: prob = predictor.predict(...); prob = bayesian_adjustment(prob, n_obs, a, b)
-    double prob = static_cast<double>(sc);
-    if (p.risk) prob = bayes_adjust1(prob, p.n_obs, p.alpha, p.beta);
-    if (p.p_hist) {
-        double* ph = p.p_hist + static_cast<int64_t>(b) * p.L;
-        ph[p.stage_idx] = prob;
-        if (p.k_star || p.stop) {
-            const int n_dp = p.prefix ? p.stage_idx + 1 : p.L;       // pipeline.py:248-256 uses the prefix
-            double pp[ASD_MAX_STAGES], cc[ASD_MAX_STAGES], J[ASD_MAX_STAGES + 1];
-#pragma unroll
-            for (int i = 0; i < ASD_MAX_STAGES; ++i) {
-                if (i < n_dp) { pp[i] = (i == p.stage_idx) ? prob : ph[i]; cc[i] = p.C[i]; }
-            }
-            const int ks = optimal_stopping1(pp, cc, p.lam, n_dp, 0, 1.0, 1.0, J);
-            if (p.k_star) p.k_star[b] = ks;
-            if (p.stop) p.stop[b] = (ks == p.stage_idx) ? 1 : 0;     // pipeline.py:259
-        }
-    }
-    if (p.theta && p.thr_stop) {
-        const double q = static_cast<double>(sc);                    // minimal_adaptive_decoder.py:159-161
-        p.thr_stop[b] = (q >= p.theta[p.stage_idx] || p.stage_idx == p.L - 1) ? 1 : 0;
-    }
-}
-
+// ---- fused epilogue: one wave per sequence (shared pieces: predictor_device.hpp) ----------
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_predictor_stop(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -313,65 +182,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_predictor_stop(const Fu
 }
 
 // Latency form for the reference's predictor (64 -> 32 -> 1) and K <= 64: one wave per sequence,
-// every global load issued up front, the first layer split over the two half-waves with its
-// weights in registers (32 per lane).  This is what a decode step calls (B = tens of sequences):
-// the work is a few thousand flops, so the only thing that matters is the length of the
-// dependency chain.
+// every global load issued up front (predictor_device.hpp: epi_prefetch / epi_finish).  This is
+// what a decode step calls (B = tens of sequences): the work is a few thousand flops, so the only
+// thing that matters is the length of the dependency chain.
 __global__ __launch_bounds__(64) void k_predictor_stop_w64x32(const FusedParams p) {
     __shared__ double dvals[3 * 64];
     __shared__ __attribute__((aligned(16))) float xs[64];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const bool want_stats = p.lp && (p.stats_col >= 0 || p.stats);
-    // ---- phase 0: loads
     int n = p.K;
     if (want_stats && p.n_valid) n = p.n_valid[b];
     float lpv = 0.0f;
     if (want_stats && lane < p.K) lpv = p.lp[static_cast<int64_t>(b) * p.ld_lp + lane];
-    float xv = p.feat[static_cast<int64_t>(b) * p.ldf + lane];
-    const int j = lane & 31, half = lane >> 5;
-    float w[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) w[i] = p.packed[(half * 32 + i) * 32 + j];
-    const float b1 = p.packed[64 * 32 + j];
-    const float w2 = p.packed[64 * 32 + 32 + j];
-    const float b2 = p.packed[64 * 32 + 64];
-    // ---- phase 1: statistics of the log-probs
+    EpiPrefetch e;
+    epi_prefetch(p, b, lane, e);
     n = n < 0 ? 0 : (n > p.K ? p.K : n);
-    double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (want_stats) {
-        if (lane < n) dvals[lane] = static_cast<double>(lpv);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        wave_logprob_stats(dvals, dvals + 64, dvals + 128, n, lane, st);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) st[i] = __shfl(st[i], 0, 64);
-        if (p.stats && lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
-        }
-        const int si = lane - p.stats_col;
-        if (p.stats_col >= 0 && si >= 0 && si < 5)
-            xv = static_cast<float>(si == 0 ? st[0] : si == 1 ? st[1] : si == 2 ? st[2] : si == 3 ? st[3] : st[4]);
-    }
-    xs[lane] = xv;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- phase 2: MLP
-    float h = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) h = fmaf(w[i], xs[half * 32 + i], h);
-    h += __shfl_xor(h, 32, 64);
-    h = fmaxf(h + b1, 0.0f);
-    float z = half == 0 ? w2 * h : 0.0f;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) z += __shfl_xor(z, off, 64);
-    const float sc = 1.0f / (1.0f + expf(-(z + b2)));
-    if (lane == 0) decide_and_store(p, b, sc);
+    epi_finish(p, b, lane, lpv, n, want_stats, e, dvals, xs);
 }
-
 
 inline bool mlp_dims_ok(int in_dim, int hidden) {
     return in_dim >= 1 && hidden >= 1 && in_dim <= ASD_MAX_MLP_DIM && hidden <= ASD_MAX_MLP_DIM;

@@ -43,7 +43,7 @@
 // (softmax -> index -> log -> .item(), one token per iteration).  The acceptance test has no
 // reference symbol; it is specified in include/asd_hip.h and DESIGN.md.
 
-#include "common.hpp"
+#include "predictor_device.hpp"   // brings common.hpp; this TU is built with -ffp-contract=off
 
 #ifdef ASD_STAMP
 // Diagnostic build only (tools/stamp_verify.py builds a separate .so with -DASD_STAMP): per-workgroup
@@ -65,7 +65,8 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr double kLn2d = 0.693147180559945309417232121458;
 constexpr float kSentinel = -1.0e30f;  // "minus infinity" that stays finite under subtraction
 constexpr int kMaxStage = 1024;        // granules one finisher stages in LDS (K*S <= kMaxStage)
-constexpr int kTicketStride = 32;      // u32 units: one 128-byte line per sequence
+constexpr int kTicketStride = 64;      // u32 units: 256 bytes per sequence = ticket/ballot line + one line of K lp_t values
+constexpr int kLpLineOffset = 32;      // u32 units: where the fused epilogue's lp_t hand-off line starts
 constexpr int kFastMaxK = 32;          // ballot-by-atomic packs K flags + a 32-bit count in one u64
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -87,6 +88,8 @@ struct VerifyParams {
     uint64_t* granules;
     uint32_t region;     // granules per sequence region
     int mode;            // 0: accept, 1: emit (m2, s, g) partials
+    int fused;           // != 0: the sequence's last arriver also runs the predictor / stop epilogue (N1)
+    FusedParams epi;     // asd_predictor_stop's parameters (lp / n_valid unused: the kernel's own lp_t, all K)
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     using E = Elem<DT>;
     constexpr int kWaves = THREADS / 64;
     __shared__ uint32_t next_tile;
-    __shared__ uint64_t stage[kMaxStage];   // tile slots while streaming, granule staging for the finisher
+    __shared__ __attribute__((aligned(16))) uint64_t stage[kMaxStage];   // tile slots while streaming, then scratch of the finisher
 
     ASD_STAMP_AT(0);
 #ifdef ASD_STAMP
@@ -351,6 +354,9 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
         if (t_tok >= 0 && t_tok < p.V) x_tok = E::scalar(rowp, t_tok);
         if (p.mode == 0) lu_row = log_u(uu);
     }
+    EpiPrefetch pre;
+    const bool fused = own_row && p.fused != 0 && p.mode == 0;
+    if (fused && wave == 0) epi_prefetch(p.epi, b, lane, pre);   // features + predictor weights, also under the stream
     if (wave == 0) {
         // unaligned head / ragged tail (<= 7 elements each) of the first / last slice: slot n_tiles
         float hm = kSentinel, hs = 0.0f;
@@ -417,34 +423,53 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
 
     if (own_row) {
         // ---- one workgroup per row: finish the row here ---------------------------------------
-        if (lane != 0) return;
+        if (!fused && lane != 0) return;
         if (p.mode == 1) {
             p.msg[3 * row + 0] = m2;
             p.msg[3 * row + 1] = s;
             p.msg[3 * row + 2] = x_tok;
             return;
         }
-        float lp;
-        const bool flag = finish_row(m2, s, x_tok, lpd, lu_row, lp);
-        p.lp_t[row] = lp;
-        p.accept[row] = flag ? 1 : 0;
-        // ballot by atomic: count in the high word, this row's flag at bit k of the low word
-        uint64_t* word = reinterpret_cast<uint64_t*>(p.tickets + static_cast<int64_t>(b) * kTicketStride + 2);
-        const uint64_t mine = (1ull << 32) | (static_cast<uint64_t>(flag ? 1u : 0u) << k);
-        ASD_STAMP_AT(4);
-        const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (static_cast<uint32_t>(old >> 32) == static_cast<uint32_t>(p.K - 1)) {
-            const uint32_t mask = static_cast<uint32_t>(old | mine);
-            const uint32_t inv = ~mask;
-            const int n = inv ? __builtin_ctz(inv) : 32;
-            p.n_acc[b] = n < p.K ? n : p.K;
-            if (p.bits) p.bits[b] = mask;
-            __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        uint32_t* line = p.tickets + static_cast<int64_t>(b) * kTicketStride;
+        int last = 0;
+        if (lane == 0) {
+            float lp;
+            const bool flag = finish_row(m2, s, x_tok, lpd, lu_row, lp);
+            p.lp_t[row] = lp;
+            p.accept[row] = flag ? 1 : 0;
+            if (fused) {   // hand lp_t to whoever finishes the sequence: write-through store, drained before the ticket
+                __hip_atomic_store(line + kLpLineOffset + k, __float_as_uint(lp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // ballot by atomic: count in the high word, this row's flag at bit k of the low word
+            uint64_t* word = reinterpret_cast<uint64_t*>(line + 2);
+            const uint64_t mine = (1ull << 32) | (static_cast<uint64_t>(flag ? 1u : 0u) << k);
+            ASD_STAMP_AT(4);
+            const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (static_cast<uint32_t>(old >> 32) == static_cast<uint32_t>(p.K - 1)) {
+                last = 1;
+                const uint32_t mask = static_cast<uint32_t>(old | mine);
+                const uint32_t inv = ~mask;
+                const int n = inv ? __builtin_ctz(inv) : 32;
+                p.n_acc[b] = n < p.K ? n : p.K;
+                if (p.bits) p.bits[b] = mask;
+                __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #ifdef ASD_STAMP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (g_asd_stamps) g_asd_stamps[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime() + (old & 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (g_asd_stamps) g_asd_stamps[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime() + (old & 0);
 #endif
+        }
+        if (!fused) return;
+        last = __shfl(last, 0, 64);
+        if (!last) return;
+        // ---- last arriver of the sequence, whole wave: statistics of the K log-probs -> features ->
+        // predictor -> Bayes -> DP rule (predictor_device.hpp), on the values the K rows handed over
+        float lpv = 0.0f;
+        if (lane < p.K)
+            lpv = __uint_as_float(__hip_atomic_load(line + kLpLineOffset + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        epi_finish(p.epi, b, lane, lpv, p.K, p.epi.stats_col >= 0 || p.epi.stats != nullptr, pre,
+                   reinterpret_cast<double*>(stage), reinterpret_cast<float*>(stage + 192));
         return;
     }
 
@@ -680,6 +705,47 @@ ASD_EXPORT int asd_verify_accept_tuned(const void* logits, int dtype, int64_t ld
     p.lp_t = lp_target; p.accept = accept; p.n_acc = n_acc; p.bits = accept_bits;
     p.msg = nullptr; p.mode = 0;
     return launch_verify(p, dtype, workspace, workspace_bytes, stream, Geometry{splits, threads, unroll, nontemporal});
+}
+
+ASD_EXPORT int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,
+                                       const float* lp_draft, const float* u, int B, int K, int V, float* lp_target,
+                                       uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits, void* workspace,
+                                       size_t workspace_bytes, const float* feat, int64_t ldf, int stats_col,
+                                       const float* packed_w, int in_dim, int hidden, int risk_adjustment, int64_t n_obs,
+                                       double alpha, double beta, double* p_hist, const double* C, double lam, int L,
+                                       int stage_idx, int prefix_rule, const double* theta, float* score,
+                                       int32_t* k_star, uint8_t* stop, uint8_t* thr_stop, double* stats, void* stream) {
+    if (B > 0 && K > 0 && (!lp_draft || !u || !lp_target || !accept || !n_acc)) return ASD_ERR_INVALID_ARG;
+    if (L < 1 || stage_idx < 0 || stage_idx >= L) return ASD_ERR_INVALID_ARG;
+    if (L > ASD_MAX_STAGES) return ASD_ERR_UNSUPPORTED;
+    if (B > 0 && (!feat || !packed_w || ldf < in_dim)) return ASD_ERR_INVALID_ARG;
+    if (stats_col >= 0 && stats_col + ASD_NUM_LP_STATS > in_dim) return ASD_ERR_INVALID_ARG;
+    if ((k_star || stop) && (!p_hist || !C)) return ASD_ERR_INVALID_ARG;
+    const int64_t R = static_cast<int64_t>(B) * K;
+    const bool in_kernel = in_dim == 64 && hidden == 32 && K <= kFastMaxK && R >= current_device_cus();
+    if (!in_kernel) {   // shapes the in-kernel epilogue does not cover: same results from two launches
+        const int rc = asd_verify_accept(logits, dtype, ld_row, tok, lp_draft, u, B, K, V, lp_target, accept, n_acc,
+                                         accept_bits, workspace, workspace_bytes, stream);
+        if (rc != ASD_OK) return rc;
+        return asd_predictor_stop(lp_target, K, nullptr, K, feat, ldf, stats_col, packed_w, in_dim, hidden,
+                                  risk_adjustment, n_obs, alpha, beta, p_hist, C, lam, L, stage_idx, prefix_rule, theta, B,
+                                  score, k_star, stop, thr_stop, stats, stream);
+    }
+    VerifyParams p{};
+    p.logits = logits; p.ld_row = ld_row; p.tok = tok; p.lp_d = lp_draft; p.u = u;
+    p.B = B; p.K = K; p.V = V; p.v_offset = 0;
+    p.lp_t = lp_target; p.accept = accept; p.n_acc = n_acc; p.bits = accept_bits;
+    p.msg = nullptr; p.mode = 0; p.fused = 1;
+    FusedParams& e = p.epi;
+    e.lp = nullptr; e.ld_lp = K; e.n_valid = nullptr; e.K = K;
+    e.feat = feat; e.ldf = ldf; e.stats_col = stats_col;
+    e.packed = packed_w; e.in_dim = in_dim; e.hidden = hidden; e.use_lds = 0;
+    e.risk = risk_adjustment ? 1 : 0; e.n_obs = static_cast<double>(n_obs); e.alpha = alpha; e.beta = beta;
+    e.p_hist = p_hist; e.C = C; e.lam = lam; e.L = L; e.stage_idx = stage_idx; e.prefix = prefix_rule ? 1 : 0;
+    e.theta = theta; e.B = B;
+    e.score = score; e.k_star = k_star; e.stop = stop; e.thr_stop = thr_stop; e.stats = stats;
+    Geometry g{1, 0, 0, -1};   // the in-kernel epilogue lives on the one-workgroup-per-row path
+    return launch_verify(p, dtype, workspace, workspace_bytes, stream, g);
 }
 
 ASD_EXPORT int asd_verify_accept(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,

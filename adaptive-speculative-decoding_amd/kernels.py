@@ -282,3 +282,40 @@ def predictor_stop(feat: torch.Tensor, packed_w: torch.Tensor, in_dim: int, hidd
         None if thr is None else thr.data_ptr(), None if stats is None else stats.data_ptr(), _stream())
     B.check("asd_predictor_stop", rc)
     return StopResult(score, k_star, stop, thr, stats)
+
+
+def verify_accept_fused(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
+                        workspace: VerifyWorkspace, feat: torch.Tensor, packed_w: torch.Tensor, in_dim: int, hidden: int, *,
+                        stage_idx: int, L: int, stats_col: int = 5, risk_adjustment: bool = True, n_obs: int = 100,
+                        alpha: float = 1.0, beta: float = 1.0, p_hist: Optional[torch.Tensor] = None,
+                        Cc: Optional[torch.Tensor] = None, lam: float = 1.0, prefix_rule: bool = False,
+                        theta: Optional[torch.Tensor] = None, want_stats: bool = False,
+                        out: Optional[VerifyResult] = None) -> Tuple[VerifyResult, StopResult]:
+    """N1, second form: verify + accept + predictor/stop epilogue in ONE call (one launch when the shape is
+    covered in-kernel, two otherwise; see asd_verify_accept_fused in include/asd_hip.h)."""
+    Bv, K = tok.shape
+    V, ld, ptr = _logits_2d(logits, Bv, K)
+    dev = logits.device
+    if out is None:
+        out = VerifyResult(torch.empty((Bv, K), dtype=torch.float32, device=dev),
+                           torch.empty((Bv, K), dtype=torch.uint8, device=dev),
+                           torch.empty((Bv,), dtype=torch.int32, device=dev),
+                           torch.empty((Bv,), dtype=torch.int64, device=dev))
+    score = torch.empty((Bv,), dtype=torch.float32, device=dev)
+    dp = p_hist is not None and Cc is not None
+    k_star = torch.empty((Bv,), dtype=torch.int32, device=dev) if dp else None
+    stop = torch.empty((Bv,), dtype=torch.uint8, device=dev) if dp else None
+    thr = torch.empty((Bv,), dtype=torch.uint8, device=dev) if theta is not None else None
+    stats = torch.empty((Bv, 5), dtype=torch.float64, device=dev) if want_stats else None
+    rc = _lib().asd_verify_accept_fused(
+        ptr, _DTYPE_CODE[logits.dtype], ld, _dev(tok, "tok", torch.int32), _dev(lp_draft, "lp_draft", torch.float32),
+        _dev(u, "u", torch.float32), Bv, K, V, out.lp_target.data_ptr(), out.accept.data_ptr(), out.n_acc.data_ptr(),
+        out.accept_bits.data_ptr(), workspace.buf.data_ptr(), workspace.bytes,
+        _dev(feat, "feat", torch.float32), feat.stride(0) if Bv else in_dim, stats_col,
+        _dev(packed_w, "packed_w", torch.float32), in_dim, hidden, int(bool(risk_adjustment)), int(n_obs), float(alpha),
+        float(beta), _opt(p_hist, "p_hist", torch.float64), _opt(Cc, "C", torch.float64), float(lam), L, stage_idx,
+        int(bool(prefix_rule)), _opt(theta, "theta", torch.float64), score.data_ptr(),
+        None if k_star is None else k_star.data_ptr(), None if stop is None else stop.data_ptr(),
+        None if thr is None else thr.data_ptr(), None if stats is None else stats.data_ptr(), _stream())
+    B.check("asd_verify_accept_fused", rc)
+    return out, StopResult(score, k_star, stop, thr, stats)

@@ -177,6 +177,9 @@ def main():
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--verify-only", action="store_true", help="skip the predictor/stop epilogue launch")
+    ap.add_argument("--fused", action="store_true",
+                    help="one launch per step: asd_verify_accept_fused runs the epilogue inside the verify kernel's last "
+                         "arriver (N1 second form).  Not the default: it lengthens the verify kernel's tail")
     ap.add_argument("--mode", choices=["graph", "eager", "overlap"], default="graph",
                     help="graph: runs of steps captured in one hipGraph on one stream (default; falls back to eager if "
                          "capture fails); eager: plain launches; overlap: epilogue forked to a side stream inside the "
@@ -257,8 +260,23 @@ def main():
         if rc:
             raise RuntimeError(f"asd_predictor_stop rc={rc}")
 
+    def fused_step(buf, stream=None):
+        o = buf["out"]
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        rc = lib.asd_verify_accept_fused(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(),
+                                         buf["u"].data_ptr(), B, K, V, o.lp_target.data_ptr(), o.accept.data_ptr(),
+                                         o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes,
+                                         feat.data_ptr(), 64, 5, packed.data_ptr(), 64, 32, 1, 100, 1.0, 1.0,
+                                         p_hist.data_ptr(), Cc.data_ptr(), 1.0, N_STAGES, 0, 0, None, score.data_ptr(),
+                                         k_star.data_ptr(), stop.data_ptr(), None, None, st)
+        if rc:
+            raise RuntimeError(f"asd_verify_accept_fused rc={rc}")
+
     def step(i):
         buf = bufs[i % nbuf]
+        if args.fused:
+            fused_step(buf)
+            return
         verify(buf)
         if not args.verify_only:
             epilogue(buf)
@@ -277,6 +295,9 @@ def main():
             main = torch.cuda.current_stream()
             for j in range(count):
                 buf = bufs[(first + j) % nbuf]
+                if args.fused:
+                    fused_step(buf, main.cuda_stream)
+                    continue
                 verify(buf, main.cuda_stream)
                 if args.verify_only:
                     continue
@@ -411,8 +432,10 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}; step = asd_verify_accept"
-                                   + ("" if args.verify_only else " + asd_predictor_stop (stats->MLP->Bayes->DP)"),
+            "config": {"workload": f"{args.workload}: {desc}; step = "
+                                   + ("asd_verify_accept_fused (epilogue inside the verify launch)" if args.fused else
+                                      "asd_verify_accept" + ("" if args.verify_only else
+                                                             " + asd_predictor_stop (stats->MLP->Bayes->DP)")),
                        "batch_per_gpu": B, "draft_len": K, "vocab": V, "accumulate": "f32 (epilogue f64)",
                        "rotating_buffers": nbuf, "buffer_MB": round(B * K * V * 2 / 1e6, 2),
                        "launch_mode": args.mode if graph is not None else "eager", "steps_per_graph": G,

@@ -102,9 +102,10 @@ int asd_verify_accept_tuned(const void* logits, int dtype, int64_t ld_row,
                             int splits, int threads, int unroll, int nontemporal);
 
 /* Vocab-sharded target (lm_head split over ranks): each rank reduces its [B,K,V_shard] slice,
- * whose first column is global vocab id `v_offset`, to msg[b,k,:] = (m, s, g):
- *   m = max_v x,  s = sum_v exp(x - m),  g = x[tok - v_offset] if the token is in this shard
- *   else -inf.   One all-gather of msg ([B,K,3] f32 per rank) is the only exchange step. */
+ * whose first column is global vocab id `v_offset`, to msg[b,k,:] = (m2, s, g) with
+ *   sum_v exp(x_v) = s * 2^m2   (log2 domain: m2 = log2(e) * max_v x up to rounding, which cancels),
+ *   g = x[tok - v_offset] if the token lies in this shard, else -inf.
+ * One all-gather of msg ([B,K,3] f32 per rank) is the only exchange step. */
 int asd_lse_partial(const void* logits_shard, int dtype, int64_t ld_row,
                     const int32_t* tok /*[B,K] GLOBAL ids*/, int B, int K, int V_shard,
                     int64_t v_offset, float* msg /*[B,K,3] out*/,
@@ -195,6 +196,24 @@ int asd_predictor_stop(const float* lp /*[B,K]*/, int64_t ld_lp, const int32_t* 
                        const double* theta /*[L] or NULL*/, int B,
                        float* score /*[B]*/, int32_t* k_star /*[B]*/, uint8_t* stop /*[B]*/,
                        uint8_t* thr_stop /*[B]*/, double* stats /*[B,5]*/, void* stream);
+
+/* N1, second form: asd_verify_accept with the epilogue of asd_predictor_stop run INSIDE the same
+ * launch by the workgroup that completes each sequence (lp = the kernel's own lp_target, all K
+ * positions valid).  One launch per tier step instead of two.  The in-kernel form covers the
+ * reference's 64->32->1 predictor, K <= 32 and B*K >= the number of CUs; any other shape is served
+ * by the same call as two launches with identical results.  Parameters: those of
+ * asd_verify_accept followed by those of asd_predictor_stop (without lp / n_valid / K / B). */
+int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld_row,
+                            const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
+                            float* lp_target, uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits,
+                            void* workspace, size_t workspace_bytes,
+                            const float* feat, int64_t ldf, int stats_col,
+                            const float* packed_w, int in_dim, int hidden,
+                            int risk_adjustment, int64_t n_obs, double alpha, double beta,
+                            double* p_hist, const double* C, double lam, int L, int stage_idx, int prefix_rule,
+                            const double* theta,
+                            float* score, int32_t* k_star, uint8_t* stop, uint8_t* thr_stop, double* stats,
+                            void* stream);
 
 #ifdef __cplusplus
 }

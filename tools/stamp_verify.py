@@ -29,8 +29,8 @@ def main():
     lib_path = os.path.join(out, "libasd_hip_stamp.so")
     csrc = os.path.join(ROOT, "adaptive-speculative-decoding_amd", "csrc")
     subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-DASD_STAMP",
-                           f"-I{ROOT}/include", f"-I{csrc}", os.path.join(csrc, "verify_accept.hip"),
-                           os.path.join(csrc, "api.hip"), "-o", lib_path])
+                           "-ffp-contract=off", f"-I{ROOT}/include", f"-I{csrc}", os.path.join(csrc, "verify_accept.hip"),
+                           os.path.join(csrc, "api.hip"), os.path.join(csrc, "predictor.hip"), "-o", lib_path])
     lib = C.CDLL(lib_path)
     from asd_amd import kernels as K
     B, Kk, V, _ = WORKLOADS[wl]
