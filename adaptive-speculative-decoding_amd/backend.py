@@ -35,6 +35,10 @@ class HipBackend:
                 "torch.cuda.is_available() is False and there is no CPU fallback")
         self._torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        # verify workspaces are reused across calls, one set per calling thread (the pipeline serves
+        # requests from a thread pool; a workspace must not be shared by calls that may overlap)
+        import threading
+        self._tls = threading.local()
 
     # -- helpers
     def _up(self, a, dtype):
@@ -112,7 +116,13 @@ class HipBackend:
         lg = logits if isinstance(logits, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(logits))
         lg = lg.to(self.device)
         Bv, Kk, V = lg.shape
-        ws = K.VerifyWorkspace(Bv, Kk, V, lg.dtype, self.device)
+        cache = getattr(self._tls, "ws", None)
+        if cache is None:
+            cache = self._tls.ws = {}
+        key = (Bv, Kk, str(lg.dtype))
+        ws = cache.get(key)
+        if ws is None or ws.V < V:
+            ws = cache[key] = K.VerifyWorkspace(Bv, Kk, V, lg.dtype, self.device)
         r = K.verify_accept(lg, self._up(tok, np.int32).reshape(Bv, Kk), self._up(lp_draft, np.float32).reshape(Bv, Kk),
                             self._up(u, np.float32).reshape(Bv, Kk), ws)
         return dict(lp_t=r.lp_target.cpu().numpy(), accept=r.accept.cpu().numpy(), n_acc=r.n_acc.cpu().numpy(),
