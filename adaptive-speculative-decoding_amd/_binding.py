@@ -75,6 +75,8 @@ def load_library() -> C.CDLL:
         if _lib is not None:
             return _lib
         if not os.path.exists(LIB_PATH):
+            _build_in_tree()
+        if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built. "
                 "Run `python adaptive-speculative-decoding_amd/build.py` (needs hipcc). "
@@ -89,6 +91,20 @@ def load_library() -> C.CDLL:
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def _build_in_tree() -> None:
+    """First use on a fresh checkout: compile the library in-tree if a ROCm toolchain is present.
+    Failure is not hidden -- load_library() then raises with the build instructions."""
+    import importlib.util
+    try:
+        spec = importlib.util.spec_from_file_location("asd_amd_build", os.path.join(_HERE, "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    except Exception as e:  # noqa: BLE001
+        import sys
+        print(f"[asd_amd] in-tree build of libasd_hip.so failed: {type(e).__name__}: {e}", file=sys.stderr)
 
 
 def check(fn: str, status: int) -> None:

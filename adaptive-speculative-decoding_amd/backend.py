@@ -13,7 +13,8 @@ installs anything but `HipBackend`.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple
+import threading
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -37,7 +38,6 @@ class HipBackend:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         # verify workspaces are reused across calls, one set per calling thread (the pipeline serves
         # requests from a thread pool; a workspace must not be shared by calls that may overlap)
-        import threading
         self._tls = threading.local()
 
     # -- helpers

@@ -16,6 +16,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Bring the native artefacts up to date with the sources (no-op when they are): the HIP library
+    (hipcc cross-compiles without a GPU) and the oracle's C restatement."""
+    import importlib.util
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "asd_amd_build", os.path.join(ROOT, "adaptive-speculative-decoding_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    except Exception as e:  # noqa: BLE001  (the ABI tests will then fail loudly with the reason)
+        print(f"[conftest] libasd_hip.so build failed: {e}", file=sys.stderr)
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no device is visible, e.g. a plain `pytest tests/`."""
     try:
