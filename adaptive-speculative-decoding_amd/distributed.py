@@ -20,7 +20,7 @@ HIP kernels and there is no other implementation in this package.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.distributed as dist
