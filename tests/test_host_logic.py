@@ -326,3 +326,33 @@ def test_request_cache_surface_and_cache_hits():
     r = pipe.process_request("easy q", request_id="rid")
     assert r.cache_hits == 1 and r.output == "cached text" and sm.stages["8b"].calls == []
     pipe.shutdown()
+
+
+def test_doc_spec_predictor_and_feature_extractor():
+    """A14 (RESEARCH_PROTOCOL.md:315-409): doc-only spec, so the check is self-consistency -- the kernel-served
+    eval forward equals the plain torch module, features follow the documented formulas."""
+    import torch
+    from asd_amd.serving import FeatureExtractor, QualityPredictor
+    torch.manual_seed(3)
+    qp = QualityPredictor()
+    assert sorted(qp.state_dict()) == ["mlp.0.bias", "mlp.0.weight", "mlp.3.bias", "mlp.3.weight"]
+    fx = FeatureExtractor()
+    lps = np.log(np.array([[0.5, 0.2, 0.1, 0.1, 0.1], [0.9, 0.05, 0.03, 0.01, 0.01]]))
+    f = fx.extract("a b c", "x y", lps, 2)
+    assert f.shape == (256,) and f[1] == 3 / 2048 and f[2] == 2 / 512 and f[4] == 0.5
+    assert abs(f[0] - (-np.mean([np.sum(np.exp(lp) * lp) for lp in lps]))) < 1e-15
+    assert f[3] == np.mean([lp.max() for lp in lps]) and np.all(f[5:] == 0)
+    assert fx.extract("a", "b", None, 0)[3] == -10.0 and fx.extract("a", "b", [], 0)[0] == 0.0
+    x = torch.randn(7, 256)
+    with torch.no_grad():
+        want = qp.mlp(x).numpy()
+    np.testing.assert_allclose(qp(x).numpy(), want, atol=1e-5, rtol=0)
+    p = qp.predict(prompt="a b c", draft_output="x y", draft_logprobs=lps, stage_id=2, feature_extractor=fx)
+    with torch.no_grad():
+        ref = qp.mlp(torch.from_numpy(f.astype(np.float32))[None]).item()
+    assert abs(p - ref) < 1e-5
+    # the pipeline accepts it as its predictor
+    pipe = AdaptiveSpeculativePipeline(FakeStageManager(), qp, fx, PipelineConfig(stop_rule="full", lambda_value=5.0))
+    r = pipe.process_request("easy question")
+    assert 0 <= r.stopped_at_stage < 4
+    pipe.shutdown()
