@@ -22,7 +22,7 @@ MAX_SPLITS = 64
 MAX_MLP_DIM = 1024
 NUM_LP_STATS = 5
 
-_vp, _i, _i64, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+_vp, _i, _i64, _d, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t, C.c_float
 
 # name -> (restype, argtypes); mirrors include/asd_hip.h declaration by declaration
 SIGNATURES = {
@@ -32,13 +32,12 @@ SIGNATURES = {
     "asd_verify_accept_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "asd_workspace_init": (_i, [_vp, _sz, _vp]),
     "asd_verify_accept": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "asd_verify_accept_tuned": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
-                                     _vp, _i, _i, _i, _i]),
+    "asd_verify_accept_ex": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "asd_verify_accept_fused": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                      _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d, _i, _i, _i, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp]),
-    "asd_lse_partial": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
-    "asd_accept_from_partials": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "asd_lse_partial": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
+    "asd_accept_from_partials": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
     "asd_mlp_packed_floats": (_sz, [_i, _i]),
     "asd_mlp_pack_weights": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -51,6 +50,17 @@ SIGNATURES = {
     "asd_predictor_stop": (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d,
                                 _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+class VerifyOptions(C.Structure):
+    """asd_verify_options (include/asd_hip.h)."""
+    _fields_ = [("inv_temperature", C.c_float), ("splits", C.c_int), ("threads", C.c_int), ("unroll", C.c_int),
+                ("nontemporal", C.c_int)]
+
+
+def verify_options(inv_temperature: float = 1.0, splits: int = 0, threads: int = 0, unroll: int = 0,
+                   nontemporal: int = -1) -> VerifyOptions:
+    return VerifyOptions(float(inv_temperature), int(splits), int(threads), int(unroll), int(nontemporal))
 
 
 class AsdError(RuntimeError):

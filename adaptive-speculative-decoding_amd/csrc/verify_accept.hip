@@ -87,6 +87,7 @@ struct VerifyParams {
     uint32_t* tickets;   // one 128-byte line per sequence: u32 ticket at +0, u64 ballot word at +8
     uint64_t* granules;
     uint32_t region;     // granules per sequence region
+    float scale2;        // log2(e) / temperature
     int mode;            // 0: accept, 1: emit (m2, s, g) partials
     int fused;           // != 0: the sequence's last arriver also runs the predictor / stop epilogue (N1)
     FusedParams epi;     // asd_predictor_stop's parameters (lp / n_valid unused: the kernel's own lp_t, all K)
@@ -138,34 +139,35 @@ __device__ __forceinline__ void wave_merge(float& m2, float& s) {
     m2 = M;
 }
 
-__device__ __forceinline__ void accum_scalar(float x, float& m2, float& s) {
-    const float M = fmaxf(m2, x * kLog2e);
-    s = fmaf(s, fast_exp2(m2 - M), fast_exp2(fmaf(x, kLog2e, -M)));
+// c2 = log2(e) / temperature: the per-element FMA constant, so temperature scaling costs nothing
+__device__ __forceinline__ void accum_scalar(float x, float c2, float& m2, float& s) {
+    const float M = fmaxf(m2, x * c2);
+    s = fmaf(s, fast_exp2(m2 - M), fast_exp2(fmaf(x, c2, -M)));
     m2 = M;
 }
 
-__device__ __forceinline__ void accum8(const float (&x)[8], float& m2, float& s) {
+__device__ __forceinline__ void accum8(const float (&x)[8], float c2, float& m2, float& s) {
     float vmax = max3(x[0], x[1], x[2]);
     vmax = max3(vmax, x[3], x[4]);
     vmax = max3(vmax, x[5], x[6]);
     vmax = fmaxf(vmax, x[7]);
-    const float M = fmaxf(m2, vmax * kLog2e);
+    const float M = fmaxf(m2, vmax * c2);
     const float scale = fast_exp2(m2 - M);
     float e[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = fast_exp2(fmaf(x[i], kLog2e, -M));
+    for (int i = 0; i < 8; ++i) e[i] = fast_exp2(fmaf(x[i], c2, -M));
     const float sum = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
     s = fmaf(s, scale, sum);
     m2 = M;
 }
 
-__device__ __forceinline__ void accum4(const float (&x)[4], float& m2, float& s) {
+__device__ __forceinline__ void accum4(const float (&x)[4], float c2, float& m2, float& s) {
     const float vmax = fmaxf(max3(x[0], x[1], x[2]), x[3]);
-    const float M = fmaxf(m2, vmax * kLog2e);
+    const float M = fmaxf(m2, vmax * c2);
     const float scale = fast_exp2(m2 - M);
     float e[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = fast_exp2(fmaf(x[i], kLog2e, -M));
+    for (int i = 0; i < 4; ++i) e[i] = fast_exp2(fmaf(x[i], c2, -M));
     s = fmaf(s, scale, (e[0] + e[1]) + (e[2] + e[3]));
     m2 = M;
 }
@@ -181,14 +183,14 @@ struct Elem<ASD_DTYPE_BF16> {
     static __device__ __forceinline__ float scalar(const void* p, int64_t i) {
         return __uint_as_float(static_cast<uint32_t>(static_cast<const uint16_t*>(p)[i]) << 16);
     }
-    static __device__ __forceinline__ void accum(const u32x4& v, float& m2, float& s) {
+    static __device__ __forceinline__ void accum(const u32x4& v, float c2, float& m2, float& s) {
         float x[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             x[2 * i] = __uint_as_float(v[i] << 16);
             x[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
         }
-        accum8(x, m2, s);
+        accum8(x, c2, m2, s);
     }
 };
 
@@ -200,7 +202,7 @@ struct Elem<ASD_DTYPE_F16> {
     static __device__ __forceinline__ float scalar(const void* p, int64_t i) {
         return static_cast<float>(static_cast<const _Float16*>(p)[i]);
     }
-    static __device__ __forceinline__ void accum(const u32x4& v, float& m2, float& s) {
+    static __device__ __forceinline__ void accum(const u32x4& v, float c2, float& m2, float& s) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         float x[8];
 #pragma unroll
@@ -210,7 +212,7 @@ struct Elem<ASD_DTYPE_F16> {
             x[2 * i] = static_cast<float>(h[0]);
             x[2 * i + 1] = static_cast<float>(h[1]);
         }
-        accum8(x, m2, s);
+        accum8(x, c2, m2, s);
     }
 };
 
@@ -222,11 +224,11 @@ struct Elem<ASD_DTYPE_F32> {
     static __device__ __forceinline__ float scalar(const void* p, int64_t i) {
         return static_cast<const float*>(p)[i];
     }
-    static __device__ __forceinline__ void accum(const u32x4& v, float& m2, float& s) {
+    static __device__ __forceinline__ void accum(const u32x4& v, float c2, float& m2, float& s) {
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] = __uint_as_float(v[i]);
-        accum4(x, m2, s);
+        accum4(x, c2, m2, s);
     }
 };
 
@@ -253,10 +255,12 @@ __device__ __forceinline__ double log2_split(float x) {
 __device__ __forceinline__ double log_u(float u) {
     return kLn2d * log2_split(u);  // u == 0 -> -inf (accepts), u < 0 -> NaN (rejects)
 }
-__device__ __forceinline__ bool finish_row(float m2, float s, float x_tok, float lp_d, double lu,
+__device__ __forceinline__ bool finish_row(float m2, float s, float x_tok, float c2, float lp_d, double lu,
                                            float& lp_out) {
-    const double lse = kLn2d * (static_cast<double>(m2) + log2_split(s));
-    const double lp = static_cast<double>(x_tok) - lse;
+    // everything in the log2 domain with the SAME constant c2 the stream used, so its rounding cancels:
+    // lp = ln2 * (x_tok*c2 - (m2 + log2 s)) = log softmax(a*x)[tok] exactly for a = c2*ln2 (= 1/T to 6e-8)
+    const double l2 = static_cast<double>(m2) + log2_split(s);
+    const double lp = kLn2d * (static_cast<double>(x_tok) * static_cast<double>(c2) - l2);
     lp_out = static_cast<float>(lp);
     return lu <= lp - static_cast<double>(lp_d);
 }
@@ -273,7 +277,7 @@ __device__ __forceinline__ void finish_sequence(bool flag, int lane, int K, int 
 }
 
 template <int DT, int UNROLL, bool CHECK>
-__device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, uint32_t end, float& m2, float& s) {
+__device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, uint32_t end, float c2, float& m2, float& s) {
     using E = Elem<DT>;
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) {
@@ -283,7 +287,7 @@ __device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, 
             const u32x4 neg = {E::kNegInfWord, E::kNegInfWord, E::kNegInfWord, E::kNegInfWord};
             v = ok ? v : neg;
         }
-        E::accum(v, m2, s);
+        E::accum(v, c2, m2, s);
     }
 }
 
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int S = p.S;
+    const float c2 = p.scale2;
     const int64_t bid = blockIdx.x;
     const int row = static_cast<int>(bid / S);
     const int split = static_cast<int>(bid - static_cast<int64_t>(row) * S);
@@ -360,9 +365,9 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     if (wave == 0) {
         // unaligned head / ragged tail (<= 7 elements each) of the first / last slice: slot n_tiles
         float hm = kSentinel, hs = 0.0f;
-        if (split == 0 && lane < head) accum_scalar(E::scalar(rowp, lane), hm, hs);
+        if (split == 0 && lane < head) accum_scalar(E::scalar(rowp, lane), c2, hm, hs);
         if (split == S - 1 && lane >= 32 && lane - 32 < tail)
-            accum_scalar(E::scalar(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + (lane - 32)), hm, hs);
+            accum_scalar(E::scalar(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + (lane - 32)), c2, hm, hs);
         wave_merge(hm, hs);
         if (lane == 0) stage[n_tiles] = (static_cast<uint64_t>(__float_as_uint(hs)) << 32) | __float_as_uint(hm);
     }
@@ -377,8 +382,8 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
 #define ASD_REDUCE_TILE(reg, t)                                                                          \
     do {                                                                                                 \
         float tm_ = kSentinel, ts_ = 0.0f;                                                               \
-        if ((t) < n_full) consume<DT, UNROLL, false>(reg, (t) * kTileBytes + lane_off, end, tm_, ts_);   \
-        else consume<DT, UNROLL, true>(reg, (t) * kTileBytes + lane_off, end, tm_, ts_);                 \
+        if ((t) < n_full) consume<DT, UNROLL, false>(reg, (t) * kTileBytes + lane_off, end, c2, tm_, ts_);   \
+        else consume<DT, UNROLL, true>(reg, (t) * kTileBytes + lane_off, end, c2, tm_, ts_);                 \
         wave_merge(tm_, ts_);                                                                            \
         if (lane == 0) stage[(t)] = (static_cast<uint64_t>(__float_as_uint(ts_)) << 32) | __float_as_uint(tm_); \
     } while (0)
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
         int last = 0;
         if (lane == 0) {
             float lp;
-            const bool flag = finish_row(m2, s, x_tok, lpd, lu_row, lp);
+            const bool flag = finish_row(m2, s, x_tok, c2, lpd, lu_row, lp);
             p.lp_t[row] = lp;
             p.accept[row] = flag ? 1 : 0;
             if (fused) {   // hand lp_t to whoever finishes the sequence: write-through store, drained before the ticket
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     bool flag = false;
     if (lane < p.K) {
         float lp;
-        flag = finish_row(fm, fs, x_tok, lpd, log_u(uu), lp);
+        flag = finish_row(fm, fs, x_tok, c2, lpd, log_u(uu), lp);
         p.lp_t[frow] = lp;
         p.accept[frow] = flag ? 1 : 0;
     }
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
 
 // combine all-gathered per-shard partials; one wave per sequence
 __global__ __launch_bounds__(64) void k_accept_from_partials(const float* msg_all, int n_shards, const float* lp_d,
-                                                             const float* u, int B, int K, float* lp_t,
+                                                             const float* u, int B, int K, float c2, float* lp_t,
                                                              uint8_t* accept, int32_t* n_acc, uint64_t* bits) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(64) void k_accept_from_partials(const float* msg_al
             g = (gr != gr) ? gr : fmaxf(g, gr);  // a NaN logit must not be dropped by max
         }
         float lp;
-        flag = finish_row(m2, s, g, lp_d[row], log_u(u[row]), lp);
+        flag = finish_row(m2, s, g, c2, lp_d[row], log_u(u[row]), lp);
         lp_t[row] = lp;
         accept[row] = flag ? 1 : 0;
     }
@@ -693,18 +698,35 @@ ASD_EXPORT int asd_workspace_init(void* workspace, size_t workspace_bytes, void*
     return ASD_OK;
 }
 
-ASD_EXPORT int asd_verify_accept_tuned(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,
-                                       const float* lp_draft, const float* u, int B, int K, int V,
-                                       float* lp_target, uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits,
-                                       void* workspace, size_t workspace_bytes, void* stream, int splits,
-                                       int threads, int unroll, int nontemporal) {
+namespace {
+// options -> (scale2, geometry); NULL = defaults
+int unpack_options(const asd_verify_options* opt, float& scale2, asd::Geometry& g) {
+    g = asd::Geometry{0, 0, 0, -1};
+    double inv_t = 1.0;
+    if (opt) {
+        if (!(opt->inv_temperature > 0.0f) || !(opt->inv_temperature < 3.0e38f)) return ASD_ERR_INVALID_ARG;
+        inv_t = static_cast<double>(opt->inv_temperature);
+        g = asd::Geometry{opt->splits, opt->threads, opt->unroll, opt->nontemporal};
+    }
+    scale2 = static_cast<float>(1.4426950408889634074 * inv_t);
+    return ASD_OK;
+}
+}  // namespace
+
+ASD_EXPORT int asd_verify_accept_ex(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,
+                                    const float* lp_draft, const float* u, int B, int K, int V, float* lp_target,
+                                    uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits, void* workspace,
+                                    size_t workspace_bytes, const asd_verify_options* opt, void* stream) {
     if (B > 0 && K > 0 && (!lp_draft || !u || !lp_target || !accept || !n_acc)) return ASD_ERR_INVALID_ARG;
     VerifyParams p{};
+    Geometry g;
+    const int rc = unpack_options(opt, p.scale2, g);
+    if (rc != ASD_OK) return rc;
     p.logits = logits; p.ld_row = ld_row; p.tok = tok; p.lp_d = lp_draft; p.u = u;
     p.B = B; p.K = K; p.V = V; p.v_offset = 0;
     p.lp_t = lp_target; p.accept = accept; p.n_acc = n_acc; p.bits = accept_bits;
     p.msg = nullptr; p.mode = 0;
-    return launch_verify(p, dtype, workspace, workspace_bytes, stream, Geometry{splits, threads, unroll, nontemporal});
+    return launch_verify(p, dtype, workspace, workspace_bytes, stream, g);
 }
 
 ASD_EXPORT int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,
@@ -735,7 +757,7 @@ ASD_EXPORT int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld
     p.logits = logits; p.ld_row = ld_row; p.tok = tok; p.lp_d = lp_draft; p.u = u;
     p.B = B; p.K = K; p.V = V; p.v_offset = 0;
     p.lp_t = lp_target; p.accept = accept; p.n_acc = n_acc; p.bits = accept_bits;
-    p.msg = nullptr; p.mode = 0; p.fused = 1;
+    p.msg = nullptr; p.mode = 0; p.fused = 1; p.scale2 = kLog2e;
     FusedParams& e = p.epi;
     e.lp = nullptr; e.ld_lp = K; e.n_valid = nullptr; e.K = K;
     e.feat = feat; e.ldf = ldf; e.stats_col = stats_col;
@@ -752,15 +774,17 @@ ASD_EXPORT int asd_verify_accept(const void* logits, int dtype, int64_t ld_row, 
                                  const float* lp_draft, const float* u, int B, int K, int V, float* lp_target,
                                  uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-    return asd_verify_accept_tuned(logits, dtype, ld_row, tok, lp_draft, u, B, K, V, lp_target, accept, n_acc,
-                                   accept_bits, workspace, workspace_bytes, stream, 0, 0, 0, -1);
+    return asd_verify_accept_ex(logits, dtype, ld_row, tok, lp_draft, u, B, K, V, lp_target, accept, n_acc, accept_bits,
+                                workspace, workspace_bytes, nullptr, stream);
 }
 
 ASD_EXPORT int asd_lse_partial(const void* logits_shard, int dtype, int64_t ld_row, const int32_t* tok, int B, int K,
-                               int V_shard, int64_t v_offset, float* msg, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+                               int V_shard, int64_t v_offset, float inv_temperature, float* msg, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     if (B > 0 && K > 0 && !msg) return ASD_ERR_INVALID_ARG;
+    if (!(inv_temperature > 0.0f) || !(inv_temperature < 3.0e38f)) return ASD_ERR_INVALID_ARG;
     VerifyParams p{};
+    p.scale2 = static_cast<float>(1.4426950408889634074 * static_cast<double>(inv_temperature));
     p.logits = logits_shard; p.ld_row = ld_row; p.tok = tok;
     p.B = B; p.K = K; p.V = V_shard; p.v_offset = v_offset;
     p.msg = msg; p.mode = 1;
@@ -768,13 +792,15 @@ ASD_EXPORT int asd_lse_partial(const void* logits_shard, int dtype, int64_t ld_r
 }
 
 ASD_EXPORT int asd_accept_from_partials(const float* msg_all, int n_shards, const float* lp_draft, const float* u,
-                                        int B, int K, float* lp_target, uint8_t* accept, int32_t* n_acc,
-                                        uint64_t* accept_bits, void* stream) {
+                                        int B, int K, float inv_temperature, float* lp_target, uint8_t* accept,
+                                        int32_t* n_acc, uint64_t* accept_bits, void* stream) {
     if (B < 0 || K < 0 || n_shards < 1) return ASD_ERR_INVALID_ARG;
+    if (!(inv_temperature > 0.0f) || !(inv_temperature < 3.0e38f)) return ASD_ERR_INVALID_ARG;
+    const float c2 = static_cast<float>(1.4426950408889634074 * static_cast<double>(inv_temperature));
     if (B == 0 || K == 0) return ASD_OK;
     if (K > ASD_MAX_DRAFT_LEN) return ASD_ERR_UNSUPPORTED;
     if (!msg_all || !lp_draft || !u || !lp_target || !accept || !n_acc) return ASD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_accept_from_partials, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), msg_all,
-                       n_shards, lp_draft, u, B, K, lp_target, accept, n_acc, accept_bits);
+                       n_shards, lp_draft, u, B, K, c2, lp_target, accept, n_acc, accept_bits);
     return launch_status();
 }

@@ -46,19 +46,19 @@ class HipOps:
             ws = self._ws[key] = self.K.VerifyWorkspace(B, K, V, dtype, device)
         return ws
 
-    def verify_accept(self, logits, tok, lp_d, u):
+    def verify_accept(self, logits, tok, lp_d, u, inv_temperature: float = 1.0):
         B, K = tok.shape
         ws = self._workspace(B, K, logits.shape[-1], logits.dtype, logits.device)
-        r = self.K.verify_accept(logits, tok, lp_d, u, ws)
+        r = self.K.verify_accept(logits, tok, lp_d, u, ws, inv_temperature=inv_temperature)
         return r.lp_target, r.accept, r.n_acc, r.accept_bits
 
-    def lse_partial(self, logits_shard, tok, v_offset):
+    def lse_partial(self, logits_shard, tok, v_offset, inv_temperature: float = 1.0):
         B, K = tok.shape
         ws = self._workspace(B, K, logits_shard.shape[-1], logits_shard.dtype, logits_shard.device)
-        return self.K.lse_partial(logits_shard, tok, v_offset, ws)
+        return self.K.lse_partial(logits_shard, tok, v_offset, ws, inv_temperature=inv_temperature)
 
-    def accept_from_partials(self, msg_all, lp_d, u):
-        r = self.K.accept_from_partials(msg_all, lp_d, u)
+    def accept_from_partials(self, msg_all, lp_d, u, inv_temperature: float = 1.0):
+        r = self.K.accept_from_partials(msg_all, lp_d, u, inv_temperature=inv_temperature)
         return r.lp_target, r.accept, r.n_acc, r.accept_bits
 
 
@@ -69,8 +69,9 @@ def _world(group) -> Tuple[int, int]:
 class VocabShardedVerifier:
     """Target lm_head split over the ranks of `group` along the vocabulary."""
 
-    def __init__(self, vocab: int, ops=None, group=None):
+    def __init__(self, vocab: int, ops=None, group=None, inv_temperature: float = 1.0):
         self.vocab = vocab
+        self.inv_temperature = float(inv_temperature)
         self.ops = ops if ops is not None else HipOps()
         self.group = group
         self.world, self.rank = _world(group)
@@ -81,10 +82,10 @@ class VocabShardedVerifier:
         identical on every rank (fixed combine order)."""
         if logits_shard.shape[-1] != self.v1 - self.v0:
             raise ValueError(f"rank {self.rank} expects a shard of width {self.v1 - self.v0}")
-        msg = self.ops.lse_partial(logits_shard, tok, self.v0).contiguous()
+        msg = self.ops.lse_partial(logits_shard, tok, self.v0, self.inv_temperature).contiguous()
         parts = [torch.empty_like(msg) for _ in range(self.world)]
         dist.all_gather(parts, msg, group=self.group)          # the one exchange step: [B,K,3] per rank
-        return self.ops.accept_from_partials(torch.stack(parts).contiguous(), lp_d, u)
+        return self.ops.accept_from_partials(torch.stack(parts).contiguous(), lp_d, u, self.inv_temperature)
 
 
 class BatchShardedVerifier:
@@ -97,9 +98,9 @@ class BatchShardedVerifier:
         self.batch = batch
         self.b0, self.b1 = shard_bounds(batch, self.world, self.rank)
 
-    def verify_local(self, logits, tok, lp_d, u):
+    def verify_local(self, logits, tok, lp_d, u, inv_temperature: float = 1.0):
         """Arguments are THIS rank's rows [b0:b1)."""
-        return self.ops.verify_accept(logits, tok, lp_d, u)
+        return self.ops.verify_accept(logits, tok, lp_d, u, inv_temperature)
 
     def gather_n_acc(self, n_acc_local: torch.Tensor) -> torch.Tensor:
         """Optional [B] view of the accepted lengths on every rank (token accounting)."""

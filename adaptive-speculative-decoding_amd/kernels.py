@@ -98,9 +98,10 @@ def _logits_2d(logits: torch.Tensor, Bv: int, K: int) -> Tuple[int, int, int]:
 
 
 def verify_accept(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
-                  workspace: VerifyWorkspace, out: Optional[VerifyResult] = None, *, splits: int = 0,
-                  threads: int = 0, unroll: int = 0, nontemporal: int = -1) -> VerifyResult:
-    """A5/A6 in one launch (include/asd_hip.h: asd_verify_accept).  tok/lp_draft/u: [B,K]."""
+                  workspace: VerifyWorkspace, out: Optional[VerifyResult] = None, *, inv_temperature: float = 1.0,
+                  splits: int = 0, threads: int = 0, unroll: int = 0, nontemporal: int = -1) -> VerifyResult:
+    """A5/A6 in one launch (include/asd_hip.h: asd_verify_accept_ex).  tok/lp_draft/u: [B,K].
+    inv_temperature scales the logits inside the kernel (the test runs on softmax(logits / T))."""
     Bv, K = tok.shape
     V, ld, ptr = _logits_2d(logits, Bv, K)
     dev = logits.device
@@ -109,32 +110,33 @@ def verify_accept(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tenso
                            torch.empty((Bv, K), dtype=torch.uint8, device=dev),
                            torch.empty((Bv,), dtype=torch.int32, device=dev),
                            torch.empty((Bv,), dtype=torch.int64, device=dev))
-    rc = _lib().asd_verify_accept_tuned(
+    opt = B.verify_options(inv_temperature, splits, threads, unroll, nontemporal)
+    rc = _lib().asd_verify_accept_ex(
         ptr, _DTYPE_CODE[logits.dtype], ld, _dev(tok, "tok", torch.int32), _dev(lp_draft, "lp_draft", torch.float32),
         _dev(u, "u", torch.float32), Bv, K, V, _dev(out.lp_target, "lp_target", torch.float32),
         _dev(out.accept, "accept", torch.uint8), _dev(out.n_acc, "n_acc", torch.int32),
-        _dev(out.accept_bits, "accept_bits", torch.int64), workspace.buf.data_ptr(), workspace.bytes, _stream(),
-        splits, threads, unroll, nontemporal)
-    B.check("asd_verify_accept", rc)
+        _dev(out.accept_bits, "accept_bits", torch.int64), workspace.buf.data_ptr(), workspace.bytes,
+        C.addressof(opt), _stream())
+    B.check("asd_verify_accept_ex", rc)
     return out
 
 
 def lse_partial(logits_shard: torch.Tensor, tok: torch.Tensor, v_offset: int, workspace: VerifyWorkspace,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, inv_temperature: float = 1.0) -> torch.Tensor:
     """Per-shard (m2, s, g) triples, [B,K,3] f32, with sum_v exp(x) = s * 2^m2 (log2 domain)."""
     Bv, K = tok.shape
     V, ld, ptr = _logits_2d(logits_shard, Bv, K)
     if out is None:
         out = torch.empty((Bv, K, 3), dtype=torch.float32, device=logits_shard.device)
     rc = _lib().asd_lse_partial(ptr, _DTYPE_CODE[logits_shard.dtype], ld, _dev(tok, "tok", torch.int32), Bv, K, V,
-                                int(v_offset), _dev(out, "msg", torch.float32), workspace.buf.data_ptr(),
-                                workspace.bytes, _stream())
+                                int(v_offset), float(inv_temperature), _dev(out, "msg", torch.float32),
+                                workspace.buf.data_ptr(), workspace.bytes, _stream())
     B.check("asd_lse_partial", rc)
     return out
 
 
 def accept_from_partials(msg_all: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
-                         out: Optional[VerifyResult] = None) -> VerifyResult:
+                         out: Optional[VerifyResult] = None, inv_temperature: float = 1.0) -> VerifyResult:
     """msg_all: [n_shards,B,K,3] (all-gathered asd_lse_partial outputs, shard order fixed)."""
     n_shards, Bv, K, three = msg_all.shape
     assert three == 3
@@ -146,7 +148,7 @@ def accept_from_partials(msg_all: torch.Tensor, lp_draft: torch.Tensor, u: torch
                            torch.empty((Bv,), dtype=torch.int64, device=dev))
     rc = _lib().asd_accept_from_partials(_dev(msg_all, "msg_all", torch.float32), n_shards,
                                          _dev(lp_draft, "lp_draft", torch.float32), _dev(u, "u", torch.float32), Bv, K,
-                                         out.lp_target.data_ptr(), out.accept.data_ptr(), out.n_acc.data_ptr(),
+                                         float(inv_temperature), out.lp_target.data_ptr(), out.accept.data_ptr(), out.n_acc.data_ptr(),
                                          out.accept_bits.data_ptr(), _stream())
     B.check("asd_accept_from_partials", rc)
     return out

@@ -55,6 +55,7 @@ class SpeculativeVerifier:
         self.alpha, self.beta, self.n_obs = float(risk_alpha), float(risk_beta), int(n_obs)
         self.stats_col, self.prefix = stats_col, bool(prefix_rule)
         self.fused = bool(fused)          # one launch per step (asd_verify_accept_fused) instead of two
+        self.inv_temperature = 1.0        # sampling temperature of the tier pair, fused into the verify pass
         self.p_hist = torch.ones((batch, self.L), dtype=torch.float64, device=self.device)
         self.in_dim = self.hidden = 0
         self.packed = None
@@ -71,12 +72,13 @@ class SpeculativeVerifier:
 
     def verify(self, logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
                out: Optional[K.VerifyResult] = None) -> K.VerifyResult:
-        return K.verify_accept(logits, tok, lp_draft, u, self.ws, out)
+        """`logits` are RAW target logits: 1/temperature is applied inside the kernel (self.inv_temperature)."""
+        return K.verify_accept(logits, tok, lp_draft, u, self.ws, out, inv_temperature=self.inv_temperature)
 
     def step(self, logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
              feat: Optional[torch.Tensor] = None, stage_idx: int = 0, out: Optional[K.VerifyResult] = None) -> StepResult:
         """One verify + stop decision for the whole batch: two launches (one with fused=True), nothing synchronises."""
-        if self.fused and self.packed is not None and feat is not None:
+        if self.fused and self.packed is not None and feat is not None and self.inv_temperature == 1.0:
             v, s = K.verify_accept_fused(logits, tok, lp_draft, u, self.ws, feat, self.packed, self.in_dim, self.hidden,
                                          stage_idx=stage_idx, L=self.L, stats_col=self.stats_col,
                                          risk_adjustment=self.risk, n_obs=self.n_obs, alpha=self.alpha, beta=self.beta,
@@ -119,6 +121,7 @@ def speculative_generate(draft, target, prompt_ids: torch.Tensor, max_new_tokens
     dev = prompt_ids.device
     gen = torch.Generator(device=dev).manual_seed(seed)
     B, Kd = prompt_ids.shape[0], verifier.Kd
+    verifier.inv_temperature = 1.0 / temperature
     draft.reset()
     target.reset()
     seq = prompt_ids
@@ -141,9 +144,7 @@ def speculative_generate(draft, target, prompt_ids: torch.Tensor, max_new_tokens
         lp_d = torch.stack(lps, 1).contiguous()
         t_new = target(tok)                         # [B, K, V]: row k scores the token AFTER draft token k
         # logits that score draft position k: k = 0 -> t_last, k > 0 -> t_new[:, k-1]
-        score = torch.cat([t_last[:, None], t_new[:, :-1]], dim=1).contiguous()
-        if temperature != 1.0:
-            score = (score.float() / temperature).to(score.dtype)
+        score = torch.cat([t_last[:, None], t_new[:, :-1]], dim=1).contiguous()   # raw logits: no scaling pass
         u = torch.rand((B, Kd), generator=gen, device=dev)
         res = verifier.step(score, tok.to(torch.int32).contiguous(), lp_d, u, feat)
         n_acc = res.verify.n_acc.to(torch.int64)
@@ -157,7 +158,7 @@ def speculative_generate(draft, target, prompt_ids: torch.Tensor, max_new_tokens
             bonus, _ = _sample(t_new[:, -1], temperature, gen)
             commit = torch.cat([tok, bonus[:, None]], 1)
         elif need.any():
-            p_t = torch.softmax(pos_logits, -1)
+            p_t = torch.softmax(pos_logits / temperature, -1)
             p_d = torch.softmax(dls[m - 1].float() / temperature, -1)
             resid = (p_t - p_d).clamp_min(0)
             resid = torch.where(resid.sum(-1, keepdim=True) > 0, resid, p_t)

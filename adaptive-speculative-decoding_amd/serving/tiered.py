@@ -110,11 +110,10 @@ def run_target_tier(target, link: TierLink, prompt_ids: torch.Tensor, max_new_to
         tok32, lp_d = link.recv_draft(B, K, dev)
         tok = tok32.to(torch.int64)
         t_new = target(tok)
-        score = torch.cat([t_last[:, None], t_new[:, :-1]], dim=1).contiguous()
-        if temperature != 1.0:
-            score = (score.float() / temperature).to(score.dtype)
+        score = torch.cat([t_last[:, None], t_new[:, :-1]], dim=1).contiguous()   # raw logits: 1/T is applied in-kernel
         u = torch.rand((B, K), generator=gen, device=dev)
-        _, accept, n_acc, _ = ops.verify_accept(score, tok32.contiguous(), lp_d.contiguous(), u)
+        _, accept, n_acc, _ = ops.verify_accept(score, tok32.contiguous(), lp_d.contiguous(), u,
+                                                inv_temperature=1.0 / temperature)
         link.send_verdict(accept, n_acc)
         n_acc = n_acc.to(torch.int64)
         m = int(n_acc.min().item()) + 1
@@ -125,7 +124,7 @@ def run_target_tier(target, link: TierLink, prompt_ids: torch.Tensor, max_new_to
             d_row = link.recv_from_draft((B, V), torch.float32, dev)
             commit = tok[:, :m].clone()
             need = n_acc < m
-            p_t = torch.softmax(score[:, m - 1].float(), -1)
+            p_t = torch.softmax(score[:, m - 1].float() / temperature, -1)
             p_d = torch.softmax(d_row / temperature, -1)
             resid = (p_t - p_d).clamp_min(0)
             resid = torch.where(resid.sum(-1, keepdim=True) > 0, resid, p_t)

@@ -232,7 +232,10 @@ def main():
     Cc = torch.tensor(STAGE_COSTS, dtype=torch.float64, device=device)
     p_hist = torch.ones((B, N_STAGES), dtype=torch.float64, device=device)
     lib = Kmod._lib()
-    geom = (args.splits, args.threads, args.unroll, args.nontemporal)
+    import ctypes
+    from asd_amd._binding import verify_options
+    opt = verify_options(1.0, args.splits, args.threads, args.unroll, args.nontemporal)
+    opt_ptr = ctypes.addressof(opt)
 
     # pre-bound launch closures: no allocation, no Python-side tensor work inside the timed loop
     score = torch.empty((B,), dtype=torch.float32, device=device)
@@ -243,12 +246,12 @@ def main():
     def verify(buf, stream=None):
         o = buf["out"]
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        rc = lib.asd_verify_accept_tuned(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(),
-                                         buf["u"].data_ptr(), B, K, V, o.lp_target.data_ptr(), o.accept.data_ptr(),
-                                         o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes,
-                                         st, *geom)
+        rc = lib.asd_verify_accept_ex(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(),
+                                      buf["u"].data_ptr(), B, K, V, o.lp_target.data_ptr(), o.accept.data_ptr(),
+                                      o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes,
+                                      opt_ptr, st)
         if rc:
-            raise RuntimeError(f"asd_verify_accept_tuned rc={rc}")
+            raise RuntimeError(f"asd_verify_accept_ex rc={rc}")
 
     def epilogue(buf, stream=None):
         o = buf["out"]
@@ -394,11 +397,11 @@ def main():
 
             def overify(buf):
                 o = buf["out"]
-                return lib.asd_verify_accept_tuned(buf["logits"].data_ptr(), 1, oV, buf["tok"].data_ptr(),
-                                                   buf["lp_d"].data_ptr(), buf["u"].data_ptr(), oB, oK, oV,
-                                                   o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(),
-                                                   o.accept_bits.data_ptr(), ows.buf.data_ptr(), ows.bytes,
-                                                   torch.cuda.current_stream().cuda_stream, 0, 0, 0, -1)
+                return lib.asd_verify_accept(buf["logits"].data_ptr(), 1, oV, buf["tok"].data_ptr(),
+                                             buf["lp_d"].data_ptr(), buf["u"].data_ptr(), oB, oK, oV,
+                                             o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(),
+                                             o.accept_bits.data_ptr(), ows.buf.data_ptr(), ows.bytes,
+                                             torch.cuda.current_stream().cuda_stream)
             for i in range(10):
                 overify(obufs[i % onb])
             oruns = []

@@ -67,7 +67,7 @@ int asd_device_cu_count(int device);
  * sync each) with ONE streaming pass over [B,K,V], and adds the speculative-sampling test the
  * north star names (no reference symbol exists for it):
  *
- *   lse[b,k]    = log sum_v exp(logits[b,k,v])
+ *   lse[b,k]    = log sum_v exp(logits[b,k,v])                (logits / T with asd_verify_accept_ex)
  *   lp_t[b,k]   = logits[b,k,tok[b,k]] - lse[b,k]          (tok outside [0,V) => -inf)
  *   accept[b,k] = log(u[b,k]) <= lp_t[b,k] - lp_d[b,k]     (== u <= min(1, p_t/p_d))
  *   bits[b]     = sum_k accept[b,k] << k
@@ -89,17 +89,24 @@ int asd_verify_accept(const void* logits, int dtype, int64_t ld_row,
                       int32_t* n_acc /*[B] out*/, uint64_t* accept_bits /*[B] out, may be NULL*/,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* Same kernel with the launch geometry chosen by the caller (bench / tuning sweeps):
- * splits in [1,ASD_MAX_SPLITS] workgroups per row, threads in {256,512,1024},
- * unroll in {2,4,8} 16-byte loads in flight per lane, nontemporal 0/1.
- * A 0 for any of them means "use the heuristic". */
-int asd_verify_accept_tuned(const void* logits, int dtype, int64_t ld_row,
-                            const int32_t* tok, const float* lp_draft, const float* u,
-                            int B, int K, int V,
-                            float* lp_target, uint8_t* accept, int32_t* n_acc,
-                            uint64_t* accept_bits,
-                            void* workspace, size_t workspace_bytes, void* stream,
-                            int splits, int threads, int unroll, int nontemporal);
+/* Options of asd_verify_accept_ex (host struct; NULL = all defaults). */
+typedef struct asd_verify_options {
+    float inv_temperature; /* > 0.  Logits are multiplied by it INSIDE the streaming pass (it only changes the
+                              per-element FMA constant), i.e. the test is run on softmax(logits / T) without a
+                              separate scaling pass over [B,K,V].  1.0f = logits as given.  The reference samples
+                              at temperature 0.7 (generate_training_data.py:110-119, pipeline.py:94). */
+    int splits;            /* launch geometry for tuning sweeps: workgroups per row in [1,ASD_MAX_SPLITS]; 0 = heuristic */
+    int threads;           /* 256 | 512 | 1024 lanes per workgroup; 0 = heuristic */
+    int unroll;            /* tile size in KiB a wave claims at a time: 2 | 4 | 8; 0 = heuristic */
+    int nontemporal;       /* 0 | 1; -1 = heuristic */
+} asd_verify_options;
+
+int asd_verify_accept_ex(const void* logits, int dtype, int64_t ld_row,
+                         const int32_t* tok, const float* lp_draft, const float* u,
+                         int B, int K, int V,
+                         float* lp_target, uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits,
+                         void* workspace, size_t workspace_bytes,
+                         const asd_verify_options* opt /*host, may be NULL*/, void* stream);
 
 /* Vocab-sharded target (lm_head split over ranks): each rank reduces its [B,K,V_shard] slice,
  * whose first column is global vocab id `v_offset`, to msg[b,k,:] = (m2, s, g) with
@@ -108,13 +115,13 @@ int asd_verify_accept_tuned(const void* logits, int dtype, int64_t ld_row,
  * One all-gather of msg ([B,K,3] f32 per rank) is the only exchange step. */
 int asd_lse_partial(const void* logits_shard, int dtype, int64_t ld_row,
                     const int32_t* tok /*[B,K] GLOBAL ids*/, int B, int K, int V_shard,
-                    int64_t v_offset, float* msg /*[B,K,3] out*/,
+                    int64_t v_offset, float inv_temperature, float* msg /*[B,K,3] out*/,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Combine the all-gathered partials (fixed shard order => identical on every rank) and run the
  * acceptance test.  msg_all: [n_shards][B][K][3]. */
 int asd_accept_from_partials(const float* msg_all, int n_shards,
-                             const float* lp_draft, const float* u, int B, int K,
+                             const float* lp_draft, const float* u, int B, int K, float inv_temperature,
                              float* lp_target, uint8_t* accept, int32_t* n_acc,
                              uint64_t* accept_bits, void* stream);
 

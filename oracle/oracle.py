@@ -85,7 +85,7 @@ def logits_as_f32(logits: np.ndarray, dtype: int) -> np.ndarray:
 
 # ----------------------------------------------------------------------------- A5 / A6
 def verify_accept(logits: np.ndarray, dtype: int, tok, lp_d, u, B: int, K: int, V: int,
-                  ld_row: Optional[int] = None, n_threads: int = 1):
+                  ld_row: Optional[int] = None, n_threads: int = 1, inv_temperature: float = 1.0):
     """A5 (+A6).  logits: uint16 bit patterns for bf16/f16, float32 for f32; shape [B*K, ld_row].
 
     Returns dict(lp_t f32[B,K], lp_t64 f64[B,K], accept u8[B,K], n_acc i32[B], bits u64[B],
@@ -106,7 +106,8 @@ def verify_accept(logits: np.ndarray, dtype: int, tok, lp_d, u, B: int, K: int, 
     bits = np.empty(B, np.uint64)
     rc = lib.oracle_verify_accept(_p(logits), C.c_int(dtype), C.c_int64(ld_row), _p(tok), _p(lp_d),
                                   _p(u), C.c_int(B), C.c_int(K), C.c_int(V), _p(lp_t), _p(acc),
-                                  _p(n_acc), _p(bits), _p(lp_t64), _p(margin), C.c_int(n_threads))
+                                  _p(n_acc), _p(bits), _p(lp_t64), _p(margin), C.c_int(n_threads),
+                                  C.c_float(inv_temperature))
     if rc != 0:
         raise ValueError(f"oracle_verify_accept rc={rc}")
     return dict(lp_t=lp_t.reshape(B, K), lp_t64=lp_t64.reshape(B, K), accept=acc.reshape(B, K),

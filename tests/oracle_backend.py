@@ -62,15 +62,17 @@ class OracleOps:
             return logits.contiguous().view(torch.int16).numpy().view(np.uint16), O.DT_F16
         return logits.float().contiguous().numpy(), O.DT_F32
 
-    def verify_accept(self, logits, tok, lp_d, u):
+    def verify_accept(self, logits, tok, lp_d, u, inv_temperature=1.0):
         import torch
         store, dt = self._store(logits)
         B, K, V = store.shape
-        r = O.verify_accept(store.reshape(B * K, V), dt, tok.numpy(), lp_d.numpy(), u.numpy(), B, K, V)
+        r = O.verify_accept(store.reshape(B * K, V), dt, tok.numpy(), lp_d.numpy(), u.numpy(), B, K, V,
+                            inv_temperature=inv_temperature)
         return (torch.from_numpy(r["lp_t"]), torch.from_numpy(r["accept"]), torch.from_numpy(r["n_acc"]),
                 torch.from_numpy(r["bits"].view(np.int64)))
 
-    def lse_partial(self, logits_shard, tok, v_offset):
+    def lse_partial(self, logits_shard, tok, v_offset, inv_temperature=1.0):
+        assert inv_temperature == 1.0, "the gloo tests shard at temperature 1"
         import torch
         store, dt = self._store(logits_shard)
         B, K, V = store.shape
@@ -78,7 +80,7 @@ class OracleOps:
         msg[..., 0] /= np.log(2.0)
         return torch.from_numpy(msg)
 
-    def accept_from_partials(self, msg_all, lp_d, u):
+    def accept_from_partials(self, msg_all, lp_d, u, inv_temperature=1.0):
         import torch
         m = msg_all.numpy().astype(np.float64)
         R, B, K, _ = m.shape

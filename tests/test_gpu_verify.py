@@ -56,7 +56,7 @@ def test_full_size_f32_and_f16():
 @pytest.mark.parametrize("threads", [256, 512, 1024])
 @pytest.mark.parametrize("unroll", [2, 4, 8])
 def test_every_geometry_agrees(threads, unroll):
-    """All launch geometries of asd_verify_accept_tuned give the oracle's answer."""
+    """All launch geometries selectable through asd_verify_options give the oracle's answer."""
     case = make_verify_case(4, 8, 50000, O.DT_BF16, seed=5)
     for splits in (1, 2, 3, 7, 16):
         for nt in (0, 1):
@@ -310,3 +310,34 @@ def test_hipgraph_capture_and_replay(K_):
         torch.cuda.synchronize()
         assert np.array_equal(out.accept.cpu().numpy(), case["ref"]["accept"])
         assert np.array_equal(out.n_acc.cpu().numpy(), case["ref"]["n_acc"])
+
+
+@pytest.mark.parametrize("T", [0.7, 1.0, 1.6])
+@pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32])
+def test_temperature_is_applied_inside_the_kernel(K_, T, dtype):
+    """asd_verify_options.inv_temperature: the test runs on softmax(logits / T) with no scaling pass.
+    (The reference samples at temperature 0.7: generate_training_data.py:110-119.)"""
+    import torch
+    B, K, V = 40, 8, 30011
+    case = make_verify_case(B, K, V, dtype, seed=int(T * 10), scale=6.0)
+    inv_t = np.float32(1.0 / T)
+    ref = O.verify_accept(case["logits"], dtype, case["tok"], case["lp_d"], case["u"], B, K, V, n_threads=8,
+                          inv_temperature=float(inv_t))
+    lg = to_device_logits(case["logits"], dtype).view(B, K, V)
+    ws = K_.VerifyWorkspace(B, K, V, lg.dtype)
+    tok, lp_d, u = (torch.from_numpy(case[k]).cuda() for k in ("tok", "lp_d", "u"))
+    r = K_.verify_accept(lg, tok, lp_d, u, ws, inv_temperature=float(inv_t))
+    torch.cuda.synchronize()
+    got = dict(lp_t=r.lp_target.cpu().numpy(), accept=r.accept.cpu().numpy(), n_acc=r.n_acc.cpu().numpy(),
+               bits=r.accept_bits.cpu().numpy().view(np.uint64))
+    ok = ~(ref["margin"] < 1e-4)
+    assert_verify_matches(got, ref, check_mask=False)
+    assert np.array_equal(got["accept"][ok], ref["accept"][ok])
+    # vocab-sharded path at the same temperature
+    halves = [(0, 15000), (15000, V)]
+    msgs = [K_.lse_partial(lg[:, :, a:b], tok, a, ws, inv_temperature=float(inv_t)) for a, b in halves]
+    out = K_.accept_from_partials(torch.stack(msgs).contiguous(), lp_d, u, inv_temperature=float(inv_t))
+    np.testing.assert_allclose(out.lp_target.cpu().numpy(), ref["lp_t64"], rtol=1e-6, atol=1e-5)
+    assert np.array_equal(out.accept.cpu().numpy()[ok], ref["accept"][ok])
+    with pytest.raises(K_.B.AsdError):
+        K_.verify_accept(lg, tok, lp_d, u, ws, inv_temperature=0.0)

@@ -41,10 +41,11 @@ def main():
     stamps = torch.zeros((nblk * 24,), dtype=torch.int64, device=dev)
     lib.asd_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     assert lib.asd_debug_set_stamp_buffer(stamps.data_ptr()) == 0
-    fn = lib.asd_verify_accept_tuned
+    from asd_amd._binding import verify_options
+    fn = lib.asd_verify_accept_ex
     fn.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int,
-                   C.c_int, C.c_int]
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    opt = verify_options(1.0, *geom)
     st = torch.cuda.current_stream().cuda_stream
     res, xcc, waves = [], [], []
     for it in range(12):
@@ -54,7 +55,7 @@ def main():
         torch.cuda.synchronize()
         rc = fn(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(), buf["u"].data_ptr(), B, Kk,
                 V, o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(), o.accept_bits.data_ptr(),
-                ws.buf.data_ptr(), ws.bytes, st, *geom)
+                ws.buf.data_ptr(), ws.bytes, C.addressof(opt), st)
         assert rc == 0, rc
         torch.cuda.synchronize()
         raw = stamps.cpu().numpy()

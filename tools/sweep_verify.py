@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Geometry sweep of asd_verify_accept_tuned on one GPU (dev tool; results go to gpurun_out/).
+"""Geometry sweep of asd_verify_accept_ex (asd_verify_options) on one GPU (dev tool; results go to gpurun_out/).
 
     python tools/sweep_verify.py [--workload c3] [--reps 60] [--out gpurun_out/sweep.json]
 
@@ -42,11 +42,16 @@ def main():
     nbytes = algorithmic_bytes(B, Kk, V)
     rows = []
 
+    import ctypes
+    from asd_amd._binding import verify_options
+
     def launch(buf, g):
         o = buf["out"]
-        return lib.asd_verify_accept_tuned(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(),
-                                           buf["u"].data_ptr(), B, Kk, V, o.lp_target.data_ptr(), o.accept.data_ptr(),
-                                           o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes, st, *g)
+        opt = verify_options(1.0, *g)
+        return lib.asd_verify_accept_ex(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(),
+                                        buf["u"].data_ptr(), B, Kk, V, o.lp_target.data_ptr(), o.accept.data_ptr(),
+                                        o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes,
+                                        ctypes.addressof(opt), st)
 
     grid = itertools.product([int(x) for x in a.threads.split(",")], [int(x) for x in a.unroll.split(",")],
                              [int(x) for x in a.splits.split(",")], [int(x) for x in a.nt.split(",")])
