@@ -341,3 +341,48 @@ def test_temperature_is_applied_inside_the_kernel(K_, T, dtype):
     assert np.array_equal(out.accept.cpu().numpy()[ok], ref["accept"][ok])
     with pytest.raises(K_.B.AsdError):
         K_.verify_accept(lg, tok, lp_d, u, ws, inv_temperature=0.0)
+
+
+def test_c_abi_status_codes(K_):
+    """Raw calls through ctypes: every documented failure is a negative asd_status, nothing throws."""
+    import ctypes as C
+    import torch
+    from asd_amd import _binding as Bd
+    lib = Bd.load_library()
+    B, K, V = 4, 8, 4096
+    lg = torch.zeros((B, K, V), dtype=torch.bfloat16, device="cuda")
+    tok = torch.zeros((B, K), dtype=torch.int32, device="cuda")
+    f = torch.zeros((B, K), dtype=torch.float32, device="cuda")
+    acc = torch.zeros((B, K), dtype=torch.uint8, device="cuda")
+    n = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    bits = torch.zeros((B,), dtype=torch.int64, device="cuda")
+    ws = K_.VerifyWorkspace(B, K, V)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(logits=lg.data_ptr(), dtype=1, ld=V, tokp=tok.data_ptr(), b=B, k=K, v=V, wsp=ws.buf.data_ptr(), wsb=ws.bytes,
+             lp=f.data_ptr()):
+        return lib.asd_verify_accept(logits, dtype, ld, tokp, f.data_ptr(), f.data_ptr(), b, k, v, lp, acc.data_ptr(),
+                                     n.data_ptr(), bits.data_ptr(), wsp, wsb, st)
+
+    assert call() == 0
+    assert call(logits=None) == -1                     # ASD_ERR_INVALID_ARG
+    assert call(tokp=None) == -1                       # ASD_ERR_INVALID_ARG
+    assert call(lp=None) == -1
+    assert call(b=-1) == -1
+    assert call(ld=V - 1) == -1                        # rows would overlap
+    assert call(dtype=7) == -2                         # ASD_ERR_UNSUPPORTED
+    assert call(k=65, b=1) == -2
+    assert call(wsb=64) == -3                          # ASD_ERR_WORKSPACE (too small)
+    assert call(wsp=ws.buf.data_ptr() + 8) == -3       # misaligned
+    assert call(logits=lg.data_ptr() + 1) == -5        # ASD_ERR_ALIGNMENT (odd address for a 2-byte type)
+    assert call(b=0) == 0 and call(k=0) == 0           # empty problems are no-ops
+    d = torch.zeros((4, 3), dtype=torch.float64, device="cuda")
+    ks = torch.zeros((4,), dtype=torch.int32, device="cuda")
+    assert lib.asd_optimal_stopping(d.data_ptr(), d.data_ptr(), 1.0, 4, 0, 0, 1.0, 1.0, ks.data_ptr(), None, st) == -1
+    assert lib.asd_optimal_stopping(d.data_ptr(), d.data_ptr(), 1.0, 4, 17, 0, 1.0, 1.0, ks.data_ptr(), None, st) == -2
+    assert lib.asd_optimal_stopping(None, d.data_ptr(), 1.0, 4, 3, 0, 1.0, 1.0, ks.data_ptr(), None, st) == -1
+    assert lib.asd_mlp_predict(f.data_ptr(), 8, f.data_ptr(), 4, 2000, 32, f.data_ptr(), st) == -2
+    assert lib.asd_logprob_stats(f.data_ptr(), 4, None, 4, 8, d.data_ptr(), st) == -1     # ld < K
+    assert lib.asd_workspace_init(None, 256, st) == -1
+    torch.cuda.synchronize()
+    assert call() == 0                                 # the library is still healthy afterwards
