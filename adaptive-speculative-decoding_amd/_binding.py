@@ -36,6 +36,8 @@ SIGNATURES = {
     "asd_verify_accept_fused": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                      _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d, _i, _i, _i, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp]),
+    "asd_residual_sample_workspace_bytes": (_sz, [_i, _i, _i]),
+    "asd_residual_sample": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "asd_lse_partial": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
     "asd_accept_from_partials": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),

@@ -26,6 +26,7 @@ COMMON = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=
 SOURCES = {
     "api.hip": [],
     "verify_accept.hip": ["-ffp-contract=off"],   # hosts the in-kernel epilogue (predictor_device.hpp)
+    "residual_sample.hip": [],
     "decision.hip": ["-ffp-contract=off"],
     "predictor.hip": ["-ffp-contract=off"],
 }

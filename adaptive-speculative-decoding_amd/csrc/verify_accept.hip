@@ -43,7 +43,8 @@
 // (softmax -> index -> log -> .item(), one token per iteration).  The acceptance test has no
 // reference symbol; it is specified in include/asd_hip.h and DESIGN.md.
 
-#include "predictor_device.hpp"   // brings common.hpp; this TU is built with -ffp-contract=off
+#include "lse_device.hpp"
+#include "predictor_device.hpp"   // this TU is built with -ffp-contract=off (numpy / CPython parity of the epilogue)
 
 #ifdef ASD_STAMP
 // Diagnostic build only (tools/stamp_verify.py builds a separate .so with -DASD_STAMP): per-workgroup
@@ -61,15 +62,10 @@ __device__ unsigned long long* g_asd_stamps = nullptr;
 namespace asd {
 namespace {
 
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr double kLn2d = 0.693147180559945309417232121458;
-constexpr float kSentinel = -1.0e30f;  // "minus infinity" that stays finite under subtraction
 constexpr int kMaxStage = 1024;        // granules one finisher stages in LDS (K*S <= kMaxStage)
 constexpr int kTicketStride = 64;      // u32 units: 256 bytes per sequence = ticket/ballot line + one line of K lp_t values
 constexpr int kLpLineOffset = 32;      // u32 units: where the fused epilogue's lp_t hand-off line starts
 constexpr int kFastMaxK = 32;          // ballot-by-atomic packs K flags + a 32-bit count in one u64
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct VerifyParams {
     const void* logits;
@@ -93,165 +89,6 @@ struct VerifyParams {
     FusedParams epi;     // asd_predictor_stop's parameters (lp / n_valid unused: the kernel's own lp_t, all K)
 };
 
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
-
-// (m2a, sa) (+) (m2b, sb) in the log2 domain
-__device__ __forceinline__ void ms_merge(float& m2, float& s, float m2b, float sb) {
-    const float M = fmaxf(m2, m2b);
-    const float ea = fast_exp2(m2 - M);
-    const float eb = fast_exp2(m2b - M);
-    s = fmaf(s, ea, sb * eb);
-    m2 = M;
-}
-
-// ---- wave64 reductions on DPP (row_shr 1,2,4,8 then row_bcast 15 / 31: the GFX9 sequence; the
-// total lands in lane 63 and is broadcast with v_readlane).  `__shfl_xor` lowers to ds_bpermute
-// (an LDS round trip per step); a 6-step butterfly of (m2, s) pairs cost ~2 us on the kernel's
-// tail (gpurun stamps, profiles/r01_stamps_*.log), this costs a few hundred cycles.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_move(float identity, float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp_move<0x111, 0xf>(-INFINITY, v));
-    v = fmaxf(v, dpp_move<0x112, 0xf>(-INFINITY, v));
-    v = fmaxf(v, dpp_move<0x114, 0xf>(-INFINITY, v));
-    v = fmaxf(v, dpp_move<0x118, 0xf>(-INFINITY, v));
-    v = fmaxf(v, dpp_move<0x142, 0xa>(-INFINITY, v));
-    v = fmaxf(v, dpp_move<0x143, 0xc>(-INFINITY, v));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_move<0x111, 0xf>(0.0f, v);
-    v += dpp_move<0x112, 0xf>(0.0f, v);
-    v += dpp_move<0x114, 0xf>(0.0f, v);
-    v += dpp_move<0x118, 0xf>(0.0f, v);
-    v += dpp_move<0x142, 0xa>(0.0f, v);
-    v += dpp_move<0x143, 0xc>(0.0f, v);
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-// all 64 lanes' (m2, s) -> one pair, valid (uniform) in every lane: max first, ONE rescale per lane
-__device__ __forceinline__ void wave_merge(float& m2, float& s) {
-    const float M = wave_max(m2);
-    s = wave_sum(s * fast_exp2(m2 - M));
-    m2 = M;
-}
-
-// c2 = log2(e) / temperature: the per-element FMA constant, so temperature scaling costs nothing
-__device__ __forceinline__ void accum_scalar(float x, float c2, float& m2, float& s) {
-    const float M = fmaxf(m2, x * c2);
-    s = fmaf(s, fast_exp2(m2 - M), fast_exp2(fmaf(x, c2, -M)));
-    m2 = M;
-}
-
-__device__ __forceinline__ void accum8(const float (&x)[8], float c2, float& m2, float& s) {
-    float vmax = max3(x[0], x[1], x[2]);
-    vmax = max3(vmax, x[3], x[4]);
-    vmax = max3(vmax, x[5], x[6]);
-    vmax = fmaxf(vmax, x[7]);
-    const float M = fmaxf(m2, vmax * c2);
-    const float scale = fast_exp2(m2 - M);
-    float e[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = fast_exp2(fmaf(x[i], c2, -M));
-    const float sum = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
-    s = fmaf(s, scale, sum);
-    m2 = M;
-}
-
-__device__ __forceinline__ void accum4(const float (&x)[4], float c2, float& m2, float& s) {
-    const float vmax = fmaxf(max3(x[0], x[1], x[2]), x[3]);
-    const float M = fmaxf(m2, vmax * c2);
-    const float scale = fast_exp2(m2 - M);
-    float e[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = fast_exp2(fmaf(x[i], c2, -M));
-    s = fmaf(s, scale, (e[0] + e[1]) + (e[2] + e[3]));
-    m2 = M;
-}
-
-template <int DT>
-struct Elem;
-
-template <>
-struct Elem<ASD_DTYPE_BF16> {
-    static constexpr int kBytes = 2;
-    static constexpr int kPerVec = 8;
-    static constexpr uint32_t kNegInfWord = 0xFF80FF80u;
-    static __device__ __forceinline__ float scalar(const void* p, int64_t i) {
-        return __uint_as_float(static_cast<uint32_t>(static_cast<const uint16_t*>(p)[i]) << 16);
-    }
-    static __device__ __forceinline__ void accum(const u32x4& v, float c2, float& m2, float& s) {
-        float x[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            x[2 * i] = __uint_as_float(v[i] << 16);
-            x[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
-        }
-        accum8(x, c2, m2, s);
-    }
-};
-
-template <>
-struct Elem<ASD_DTYPE_F16> {
-    static constexpr int kBytes = 2;
-    static constexpr int kPerVec = 8;
-    static constexpr uint32_t kNegInfWord = 0xFC00FC00u;
-    static __device__ __forceinline__ float scalar(const void* p, int64_t i) {
-        return static_cast<float>(static_cast<const _Float16*>(p)[i]);
-    }
-    static __device__ __forceinline__ void accum(const u32x4& v, float c2, float& m2, float& s) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        float x[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t w = v[i];  // bit_cast of the vector-element lvalue itself reads element 0
-            const h2 h = __builtin_bit_cast(h2, w);
-            x[2 * i] = static_cast<float>(h[0]);
-            x[2 * i + 1] = static_cast<float>(h[1]);
-        }
-        accum8(x, c2, m2, s);
-    }
-};
-
-template <>
-struct Elem<ASD_DTYPE_F32> {
-    static constexpr int kBytes = 4;
-    static constexpr int kPerVec = 4;
-    static constexpr uint32_t kNegInfWord = 0xFF800000u;
-    static __device__ __forceinline__ float scalar(const void* p, int64_t i) {
-        return static_cast<const float*>(p)[i];
-    }
-    static __device__ __forceinline__ void accum(const u32x4& v, float c2, float& m2, float& s) {
-        float x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = __uint_as_float(v[i]);
-        accum4(x, c2, m2, s);
-    }
-};
-
-// 16-byte buffer load; lanes whose offset is >= the descriptor's num_records return 0 without a
-// memory access.  aux: 0 = default cache policy, 2 = nt (streamed, read-once data).
-template <bool NT>
-__device__ __forceinline__ u32x4 load16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, NT ? 2 : 0));
-}
-
-// log2(x) for x >= 0 with ~1e-7 ABSOLUTE error at any magnitude: exponent exactly, v_log_f32 on
-// the mantissa only, summed in f64.  x == 0 -> -inf; inf / NaN / negative propagate like log2f.
-__device__ __forceinline__ double log2_split(float x) {
-    if (!(x > 0.0f) || !(x < INFINITY)) return static_cast<double>(__builtin_amdgcn_logf(x));
-    int e;
-    const float mant = frexpf(x, &e);
-    return static_cast<double>(e) + static_cast<double>(__builtin_amdgcn_logf(mant));
-}
-
-// lse, log-prob and acceptance test of one row from its combined (m2, s) and gathered logit.
-// The sums are f64 (they mirror the oracle's structure); the two logarithms are split into an
-// exact exponent and a v_log_f32 of the mantissa, which keeps their absolute error ~1e-7 without
-// a software f64 log on the kernel's tail.
 __device__ __forceinline__ double log_u(float u) {
     return kLn2d * log2_split(u);  // u == 0 -> -inf (accepts), u < 0 -> NaN (rejects)
 }

@@ -321,3 +321,39 @@ def verify_accept_fused(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch
         None if thr is None else thr.data_ptr(), None if stats is None else stats.data_ptr(), _stream())
     B.check("asd_verify_accept_fused", rc)
     return out, StopResult(score, k_star, stop, thr, stats)
+
+
+def _rows(t: torch.Tensor, name: str) -> Tuple[int, int]:
+    """(data_ptr, row stride in elements) of a [rows, V] or [B, K, V] logits tensor with unit stride in V."""
+    if not t.is_cuda or t.dtype not in _DTYPE_CODE or t.stride(-1) != 1:
+        raise ValueError(f"{name} must be a CUDA f32/bf16/f16 tensor with unit stride along the vocabulary")
+    if t.dim() == 3 and t.stride(0) != t.shape[1] * t.stride(1):
+        raise ValueError(f"{name}: rows must be evenly spaced over (b, k)")
+    return t.data_ptr(), t.stride(-2)
+
+
+class ResidualSampler:
+    """asd_residual_sample with its workspace: the token each sequence commits after its accepted prefix."""
+
+    def __init__(self, B_: int, V: int, dtype: torch.dtype = torch.bfloat16, device: Optional[torch.device] = None):
+        self.B, self.V, self.dtype = B_, V, dtype
+        self.bytes = int(_lib().asd_residual_sample_workspace_bytes(B_, V, _DTYPE_CODE[dtype]))
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device or torch.device("cuda"))
+
+    def __call__(self, t_logits: torch.Tensor, d_logits: torch.Tensor, n_acc: torch.Tensor, r: torch.Tensor,
+                 bonus_logits: Optional[torch.Tensor] = None, inv_temperature: float = 1.0,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """t_logits / d_logits: [B,K,V]; bonus_logits: [B,V] or None; n_acc: [B] i32; r: [B] f32 -> token [B] i32."""
+        Bv, K, V = t_logits.shape
+        if d_logits.shape != t_logits.shape or d_logits.dtype != t_logits.dtype:
+            raise ValueError("t_logits and d_logits must have the same shape and dtype")
+        tp, ldt = _rows(t_logits, "t_logits")
+        dp, ldd = _rows(d_logits, "d_logits")
+        bp, ldb = (None, V) if bonus_logits is None else _rows(bonus_logits, "bonus_logits")
+        if out is None:
+            out = torch.empty((Bv,), dtype=torch.int32, device=t_logits.device)
+        rc = _lib().asd_residual_sample(tp, ldt, dp, ldd, bp, ldb, _DTYPE_CODE[t_logits.dtype],
+                                        _dev(n_acc, "n_acc", torch.int32), _dev(r, "r", torch.float32), Bv, K, V,
+                                        float(inv_temperature), out.data_ptr(), self.buf.data_ptr(), self.bytes, _stream())
+        B.check("asd_residual_sample", rc)
+        return out

@@ -11,8 +11,9 @@ arithmetic:
                [5:10] -> quality predictor -> Bayes adjustment -> DP stop rule over the tiers:
                stop[b] says whether tier `stage_idx`'s verification is final for sequence b or
                the step should be re-verified by the next (larger) tier.
-  commit       n_acc accepted tokens + one token from the target (residual distribution at the
-               first rejection, or the target's own next-token distribution when all K pass).
+  commit       n_acc accepted tokens + one token from the target: asd_residual_sample draws it from the
+               residual distribution max(0, p_t - p_d) at the first rejection, or from the target's own
+               next-token distribution when all K pass.
 
 `SpeculativeVerifier` is the device-resident state of one (draft tier, target tier) pair: work
 space, packed predictor weights, stage costs, history of adjusted probabilities.  Everything it
@@ -57,6 +58,7 @@ class SpeculativeVerifier:
         self.fused = bool(fused)          # one launch per step (asd_verify_accept_fused) instead of two
         self.inv_temperature = 1.0        # sampling temperature of the tier pair, fused into the verify pass
         self.p_hist = torch.ones((batch, self.L), dtype=torch.float64, device=self.device)
+        self.sampler = K.ResidualSampler(batch, vocab, logits_dtype, self.device)   # commit step (asd_residual_sample)
         self.in_dim = self.hidden = 0
         self.packed = None
         if predictor is not None:
@@ -149,21 +151,17 @@ def speculative_generate(draft, target, prompt_ids: torch.Tensor, max_new_tokens
         res = verifier.step(score, tok.to(torch.int32).contiguous(), lp_d, u, feat)
         n_acc = res.verify.n_acc.to(torch.int64)
         m = int(n_acc.min().item()) + 1             # lock-step commit length (keeps one KV length per model)
-        commit = tok[:, :m].clone()
-        # token m-1: the accepted draft token where n_acc >= m, else a sample from the residual
-        # max(0, p_t - p_d) at that position (standard speculative sampling)
-        need = n_acc < m
-        pos_logits = score[:, m - 1].float() if m - 1 < Kd else None
-        if m - 1 == Kd:                             # every sequence accepted all K: bonus token from the target
-            bonus, _ = _sample(t_new[:, -1], temperature, gen)
-            commit = torch.cat([tok, bonus[:, None]], 1)
-        elif need.any():
-            p_t = torch.softmax(pos_logits / temperature, -1)
-            p_d = torch.softmax(dls[m - 1].float() / temperature, -1)
-            resid = (p_t - p_d).clamp_min(0)
-            resid = torch.where(resid.sum(-1, keepdim=True) > 0, resid, p_t)
-            rs = torch.multinomial(resid / resid.sum(-1, keepdim=True), 1, generator=gen)[:, 0]
-            commit[:, m - 1] = torch.where(need, rs, commit[:, m - 1])
+        # the token every sequence emits after ITS accepted prefix: residual draw at the first rejection,
+        # bonus draw from the target's next-token logits when all K passed -- one call, raw logits in
+        r = torch.rand((B,), generator=gen, device=dev)
+        drawn = verifier.sampler(score, torch.stack(dls, 1).to(score.dtype).contiguous(), res.verify.n_acc, r,
+                                 bonus_logits=t_new[:, -1].contiguous(), inv_temperature=verifier.inv_temperature)
+        drawn = drawn.to(torch.int64)
+        if m - 1 == Kd:                             # every sequence accepted all K: K drafts + the bonus token
+            commit = torch.cat([tok, drawn[:, None]], 1)
+        else:                                       # sequences that rejected at m-1 take their draw, the others keep the draft
+            commit = tok[:, :m].clone()
+            commit[:, m - 1] = torch.where(n_acc < m, drawn, commit[:, m - 1])
         masks.append(res.verify.accept.clone())
         stops.append(None if res.stop is None or res.stop.stop is None else res.stop.stop.clone())
         if keep_inputs:

@@ -204,6 +204,24 @@ int asd_predictor_stop(const float* lp /*[B,K]*/, int64_t ld_lp, const int32_t* 
                        float* score /*[B]*/, int32_t* k_star /*[B]*/, uint8_t* stop /*[B]*/,
                        uint8_t* thr_stop /*[B]*/, double* stats /*[B,5]*/, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The token a speculative step COMMITS after its accepted prefix (no reference symbol).
+ * For sequence b with j = n_acc[b]:
+ *   j <  K : w(v) = max(0, softmax(t_logits[b,j]/T)(v) - softmax(d_logits[b,j]/T)(v))   (residual distribution;
+ *            if it is empty, i.e. p_t <= p_d everywhere, w = softmax(t_logits[b,j]/T))
+ *   j >= K : w(v) = softmax(bonus_logits[b]/T)(v)      (all drafted tokens accepted; bonus_logits NULL => token -1)
+ *   token[b] = min { v : sum_{v' <= v} w(v') > r[b] * sum_v w(v) }        (inverse CDF in vocabulary order)
+ * t_logits / d_logits: [B*K rows][V], bonus_logits: [B rows][V], all of `dtype`, rows ld_* ELEMENTS apart,
+ * 16-byte aligned and a whole number of 16-byte vectors (ASD_ERR_ALIGNMENT otherwise).  r: [B] uniforms in [0,1).
+ * workspace: >= asd_residual_sample_workspace_bytes(B, V, dtype), 256-byte aligned, no initialisation needed.
+ * ---------------------------------------------------------------------------------------- */
+size_t asd_residual_sample_workspace_bytes(int B, int V, int dtype);
+int asd_residual_sample(const void* t_logits, int64_t ld_t, const void* d_logits, int64_t ld_d,
+                        const void* bonus_logits, int64_t ld_b, int dtype,
+                        const int32_t* n_acc /*[B]*/, const float* r /*[B]*/, int B, int K, int V,
+                        float inv_temperature, int32_t* token /*[B] out*/,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* N1, second form: asd_verify_accept with the epilogue of asd_predictor_stop run INSIDE the same
  * launch by the workgroup that completes each sequence (lp = the kernel's own lp_target, all K
  * positions valid).  One launch per tier step instead of two.  The in-kernel form covers the

@@ -129,6 +129,25 @@ def lse_partial(logits: np.ndarray, dtype: int, tok, B: int, K: int, V_shard: in
     return msg
 
 
+def residual_sample(t_logits: np.ndarray, d_logits: np.ndarray, dtype: int, n_acc, r, B: int, K: int, V: int,
+                    bonus: Optional[np.ndarray] = None, inv_temperature: float = 1.0):
+    """asd_residual_sample in f64.  t_logits / d_logits: storage arrays [B*K, V]; bonus: [B, V] or None.
+    Returns (token i32[B], margin f64[B])."""
+    lib = _load()
+    t_logits, d_logits = np.ascontiguousarray(t_logits), np.ascontiguousarray(d_logits)
+    bonus = None if bonus is None else np.ascontiguousarray(bonus)
+    n_acc = _c(n_acc, np.int32).reshape(-1)
+    r = _c(r, np.float32).reshape(-1)
+    tok = np.empty(B, np.int32)
+    margin = np.empty(B, np.float64)
+    rc = lib.oracle_residual_sample(_p(t_logits), C.c_int64(V), _p(d_logits), C.c_int64(V), _p(bonus), C.c_int64(V),
+                                    C.c_int(dtype), _p(n_acc), _p(r), C.c_int(B), C.c_int(K), C.c_int(V),
+                                    C.c_float(inv_temperature), _p(tok), _p(margin))
+    if rc != 0:
+        raise ValueError(rc)
+    return tok, margin
+
+
 def py_token_logprob_reference_idiom(score_row_f32: np.ndarray, token_id: int) -> float:
     """generate_training_data.py:131-133 restated with numpy in the row's own precision:
     probs = softmax(score[0]); logprob = log(probs[token_id])."""

@@ -1,0 +1,90 @@
+"""asd_residual_sample (the token committed after the accepted prefix) against the f64 oracle.
+No reference symbol exists: parity unpinned; integer result, so the bar is bit-exact
+on the draws whose distance to a CDF edge exceeds 1e-5 of the total mass, and membership of the
+support everywhere."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import encode_logits, to_device_logits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K_():
+    from asd_amd import kernels
+    return kernels
+
+
+def _case(B, K, V, dtype, seed, spread=1.0):
+    rng = np.random.default_rng(seed)
+    xt = (rng.standard_normal((B * K, V)) * 3).astype(np.float32)
+    xd = (xt + rng.standard_normal((B * K, V)) * spread).astype(np.float32)
+    bonus = (rng.standard_normal((B, V)) * 3).astype(np.float32)
+    n_acc = rng.integers(0, K + 1, B).astype(np.int32)
+    r = rng.uniform(0, 1, B).astype(np.float32)
+    return encode_logits(xt, dtype), encode_logits(xd, dtype), encode_logits(bonus, dtype), n_acc, r
+
+
+def _gpu(K_, st, sd, sb, n_acc, r, B, K, V, dtype, inv_t=1.0, with_bonus=True):
+    import torch
+    t = to_device_logits(st, dtype).view(B, K, V)
+    d = to_device_logits(sd, dtype).view(B, K, V)
+    bo = to_device_logits(sb, dtype).view(B, V) if with_bonus else None
+    samp = K_.ResidualSampler(B, V, t.dtype)
+    out = samp(t, d, torch.from_numpy(n_acc).cuda(), torch.from_numpy(r).cuda(), bo, inv_t)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32, O.DT_F16])
+@pytest.mark.parametrize("B,K,V", [(32, 8, 152064), (5, 4, 1000), (3, 2, 8), (64, 8, 32000), (300, 3, 4096)])
+def test_residual_sample_matches_oracle(K_, dtype, B, K, V):
+    st, sd, sb, n_acc, r = _case(B, K, V, dtype, seed=B + V)
+    want, margin = O.residual_sample(st, sd, dtype, n_acc, r, B, K, V, bonus=sb)
+    got = _gpu(K_, st, sd, sb, n_acc, r, B, K, V, dtype)
+    ok = margin > 1e-5
+    assert ok.mean() > 0.5            # at V = 152064 many tokens own less than 2e-5 of the mass
+    assert np.array_equal(got[ok], want[ok])
+    # everywhere: the token lies in the support of the distribution it was drawn from
+    xt = O.logits_as_f32(st, dtype).astype(np.float64)
+    xd = O.logits_as_f32(sd, dtype).astype(np.float64)
+    for b in np.where(~ok)[0]:
+        assert abs(int(got[b]) - int(want[b])) <= 64 * 8       # a boundary case can only move to a neighbour
+        j = n_acc[b]
+        if j < K:
+            def sm(x):
+                e = np.exp(x - x.max())
+                return e / e.sum()
+            assert sm(xt[b * K + j])[got[b]] > 0
+
+
+def test_temperature_degenerate_and_missing_bonus(K_):
+    B, K, V = 16, 4, 8192
+    st, sd, sb, n_acc, r = _case(B, K, V, O.DT_BF16, seed=9)
+    for inv_t in (0.5, 1.0 / 0.7):
+        want, margin = O.residual_sample(st, sd, O.DT_BF16, n_acc, r, B, K, V, bonus=sb, inv_temperature=np.float32(inv_t))
+        got = _gpu(K_, st, sd, sb, n_acc, r, B, K, V, O.DT_BF16, inv_t=float(np.float32(inv_t)))
+        ok = margin > 1e-5
+        assert np.array_equal(got[ok], want[ok])
+    # identical target and draft rows: the residual is empty, the draw falls back to p_t
+    n0 = np.zeros(B, np.int32)
+    want, margin = O.residual_sample(st, st, O.DT_BF16, n0, r, B, K, V, bonus=sb)
+    got = _gpu(K_, st, st, sb, n0, r, B, K, V, O.DT_BF16)
+    assert np.array_equal(got[margin > 1e-5], want[margin > 1e-5])
+    # every token accepted but no bonus logits supplied: -1
+    nK = np.full(B, K, np.int32)
+    assert (_gpu(K_, st, sd, sb, nK, r, B, K, V, O.DT_BF16, with_bonus=False) == -1).all()
+    # r = 0 picks the first token with mass, r -> 1 the last
+    r0 = np.zeros(B, np.float32)
+    want, _ = O.residual_sample(st, sd, O.DT_BF16, n_acc, r0, B, K, V, bonus=sb)
+    assert np.array_equal(_gpu(K_, st, sd, sb, n_acc, r0, B, K, V, O.DT_BF16), want)
+
+
+def test_rows_must_be_whole_vectors(K_):
+    import torch
+    t = torch.zeros((2, 2, 1001), dtype=torch.bfloat16, device="cuda")
+    samp = K_.ResidualSampler(2, 1001)
+    with pytest.raises(K_.B.AsdError):
+        samp(t, t, torch.zeros(2, dtype=torch.int32, device="cuda"), torch.zeros(2, device="cuda"))

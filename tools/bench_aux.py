@@ -131,6 +131,18 @@ def main():
                                             lam=1.0), 200 if B <= 128 else 50)
         record("N1 asd_predictor_stop", B, g, B * (64 * 4 + 32 + 24 + 4 + 4 + 1), float("nan"),
                py_s8 + py_mlp + py_b + py_dp, "python idiom = stats + MLP + Bayes + DP per request")
+    # ---------------- commit step: residual / bonus draw
+    for B, Kk, V in ((32, 8, 152064), (128, 8, 152064)):
+        t = (torch.randn((B, Kk, V), device=dev) * 3).to(torch.bfloat16)
+        d = (t.float() + torch.randn((B, Kk, V), device=dev)).to(torch.bfloat16)
+        bonus = (torch.randn((B, V), device=dev) * 3).to(torch.bfloat16)
+        n_acc = torch.randint(0, Kk + 1, (B,), device=dev, dtype=torch.int32)
+        r = torch.rand((B,), device=dev)
+        samp = K.ResidualSampler(B, V)
+        out = torch.empty((B,), dtype=torch.int32, device=dev)
+        g = gpu_us(lambda: samp(t, d, n_acc, r, bonus, 1.0, out), 100)
+        record("asd_residual_sample", B, g, 2 * B * V * 2, float("nan"), float("nan"),
+               "3 launches; bytes = one pass over the B target + B draft rows (second pass is L2 / MALL traffic)")
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(dict(device=torch.cuda.get_device_name(0), rows=rows), f, indent=1)
