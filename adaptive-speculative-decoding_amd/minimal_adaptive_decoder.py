@@ -140,12 +140,24 @@ class MinimalAdaptiveDecoder:
     def _stages(self) -> List[dict]:
         return self.config["models"]["stages"]
 
+    # quality / cost of a stage whose YAML entry lacks them (the reference's own configs/qwen3_models.yaml does,
+    # and the reference then dies with KeyError): the theory's defaults by size (optimal_stopping.py:38-43)
+    _SIZE_DEFAULTS = {"7b": (0.7, 1.0), "8b": (0.7, 1.0), "13b": (0.8, 1.6), "14b": (0.8, 2.0), "32b": (0.85, 4.5),
+                      "34b": (0.85, 4.2), "70b": (0.9, 8.8), "72b": (0.9, 10.0)}
+
+    def _stage_quality_cost(self, i: int, stage: dict):
+        dq, dc = self._SIZE_DEFAULTS.get(str(stage.get("size_label", "")).lower(), (0.7 + 0.05 * i, float(2 ** i)))
+        stage.setdefault("theoretical_quality", dq)
+        stage.setdefault("relative_cost", dc)
+        return stage["theoretical_quality"], stage["relative_cost"]
+
     def _init_theory(self) -> OptimalStoppingTheory:
         stages = self._stages()
+        qc = [self._stage_quality_cost(i, s) for i, s in enumerate(stages)]
         return OptimalStoppingTheory(TheoreticalParameters(
             n_stages=len(stages),
-            quality_bounds=[s["theoretical_quality"] for s in stages],
-            cost_ratios=[s["relative_cost"] for s in stages],
+            quality_bounds=[q for q, _ in qc],
+            cost_ratios=[c for _, c in qc],
             lambda_param=1.0))
 
     def _load_models(self) -> List[dict]:

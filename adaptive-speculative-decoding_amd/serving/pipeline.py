@@ -61,6 +61,30 @@ class PipelineConfig:
     stage_names: Sequence[str] = DEFAULT_STAGE_NAMES
     stage_priors: Optional[Sequence[float]] = None          # prior p for not-yet-run stages ("full")
 
+    @classmethod
+    def from_yaml(cls, path: str) -> "PipelineConfig":
+        """Read the `pipeline:` section of a serving YAML (reference schema: configs/serving.yaml:10-30;
+        server.py:97-99 reads the same file raw).  Unknown keys are ignored."""
+        import yaml
+        with open(path, "r") as f:
+            sec = (yaml.safe_load(f) or {}).get("pipeline", {}) or {}
+        risk = sec.get("risk_adjustment", {})
+        if isinstance(risk, bool):
+            risk = {"enabled": risk}
+        kw = dict(lambda_value=float(sec.get("lambda_value", 1.0)), risk_adjustment=bool(risk.get("enabled", True)),
+                  risk_alpha=float(risk.get("alpha", 1.0)), risk_beta=float(risk.get("beta", 1.0)),
+                  enable_caching=bool((sec.get("cache", {}) or {}).get("enable_kv_cache", True)),
+                  batch_timeout_ms=float((sec.get("batching", {}) or {}).get("batch_timeout_ms", 50.0)))
+        if "max_concurrent_requests" in sec:
+            kw["max_concurrent_requests"] = int(sec["max_concurrent_requests"])
+        if "stop_rule" in sec:
+            kw["stop_rule"] = str(sec["stop_rule"])
+        if "stage_names" in sec:
+            kw["stage_names"] = tuple(sec["stage_names"])
+        if "stage_priors" in sec:
+            kw["stage_priors"] = tuple(float(x) for x in sec["stage_priors"])
+        return cls(**kw)
+
 
 @dataclass
 class RequestResult:

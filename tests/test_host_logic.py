@@ -356,3 +356,32 @@ def test_doc_spec_predictor_and_feature_extractor():
     r = pipe.process_request("easy question")
     assert 0 <= r.stopped_at_stage < 4
     pipe.shutdown()
+
+
+def test_config_surface_yaml(tmp_path):
+    """serving.yaml -> PipelineConfig; the shipped 3-tier models.yaml and the reference's own stage schema
+    (without theoretical_quality / relative_cost) both build a decoder."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = PipelineConfig.from_yaml(os.path.join(root, "configs", "serving.yaml"))
+    assert cfg.lambda_value == 1.0 and cfg.risk_adjustment is True and cfg.risk_alpha == 1.0 and cfg.risk_beta == 1.0
+    assert cfg.batch_timeout_ms == 50.0 and cfg.stop_rule == "full" and cfg.stage_names == ("7b", "32b", "72b")
+    (tmp_path / "s.yaml").write_text("pipeline:\n  lambda_value: 2.5\n  risk_adjustment:\n    enabled: false\n    alpha: 2.0\n")
+    c2 = PipelineConfig.from_yaml(str(tmp_path / "s.yaml"))
+    assert (c2.lambda_value, c2.risk_adjustment, c2.risk_alpha, c2.stop_rule) == (2.5, False, 2.0, "full")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        dec = MinimalAdaptiveDecoder(os.path.join(root, "configs", "models.yaml"))
+        assert len(dec.models) == 3 and dec.theory.params.cost_ratios == [1.0, 4.5, 10.0]
+        assert dec._theta_vector().tolist() == O.derive_thresholds([0.7, 0.85, 0.9], [1.0, 4.5, 10.0], 1.0)[0].tolist()
+        ref_style = {"models": {"stages": [{"name": "qwen3-7b", "model_path": "Qwen/Qwen3-7B-Instruct", "size_label": "7b"},
+                                           {"name": "qwen3-14b", "model_path": "x", "size_label": "14b"},
+                                           {"name": "qwen3-32b", "model_path": "x", "size_label": "32b"},
+                                           {"name": "qwen3-72b", "model_path": "x", "size_label": "72b"}]}}
+        (tmp_path / "ref.yaml").write_text(yaml.safe_dump(ref_style))
+        dec2 = MinimalAdaptiveDecoder(str(tmp_path / "ref.yaml"))
+        assert dec2.theory.params.quality_bounds == [0.7, 0.8, 0.85, 0.9]
+        assert dec2.theory.params.cost_ratios == [1.0, 2.0, 4.5, 10.0]
+        assert 0 <= dec2.decode("why?").selected_stage < 4
+    finally:
+        os.chdir(cwd)
