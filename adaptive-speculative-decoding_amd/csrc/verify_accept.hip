@@ -128,7 +128,10 @@ __device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, 
     }
 }
 
-template <int DT, int THREADS, int UNROLL, bool NT>
+// FUSED: compile-time variant that also carries the in-kernel epilogue (N1 second form).  It is a separate
+// instantiation on purpose: the epilogue's prefetch registers and code took the plain kernel from ~40 to 111
+// VGPRs and cost it 6 % (A/B in one process), so the plain kernel does not contain it at all.
+template <int DT, int THREADS, int UNROLL, bool NT, bool FUSED>
 __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     using E = Elem<DT>;
     constexpr int kWaves = THREADS / 64;
@@ -197,8 +200,10 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
         if (p.mode == 0) lu_row = log_u(uu);
     }
     EpiPrefetch pre;
-    const bool fused = own_row && p.fused != 0 && p.mode == 0;
-    if (fused && wave == 0) epi_prefetch(p.epi, b, lane, pre);   // features + predictor weights, also under the stream
+    const bool fused = FUSED && own_row && p.mode == 0;
+    if (FUSED) {
+        if (fused && wave == 0) epi_prefetch(p.epi, b, lane, pre);   // features + predictor weights, also under the stream
+    }
     if (wave == 0) {
         // unaligned head / ragged tail (<= 7 elements each) of the first / last slice: slot n_tiles
         float hm = kSentinel, hs = 0.0f;
@@ -303,15 +308,17 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
 #endif
         }
         if (!fused) return;
-        last = __shfl(last, 0, 64);
-        if (!last) return;
-        // ---- last arriver of the sequence, whole wave: statistics of the K log-probs -> features ->
-        // predictor -> Bayes -> DP rule (predictor_device.hpp), on the values the K rows handed over
-        float lpv = 0.0f;
-        if (lane < p.K)
-            lpv = __uint_as_float(__hip_atomic_load(line + kLpLineOffset + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        epi_finish(p.epi, b, lane, lpv, p.K, p.epi.stats_col >= 0 || p.epi.stats != nullptr, pre,
-                   reinterpret_cast<double*>(stage), reinterpret_cast<float*>(stage + 192));
+        if (FUSED) {
+            last = __shfl(last, 0, 64);
+            if (!last) return;
+            // ---- last arriver of the sequence, whole wave: statistics of the K log-probs -> features ->
+            // predictor -> Bayes -> DP rule (predictor_device.hpp), on the values the K rows handed over
+            float lpv = 0.0f;
+            if (lane < p.K)
+                lpv = __uint_as_float(__hip_atomic_load(line + kLpLineOffset + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            epi_finish(p.epi, b, lane, lpv, p.K, p.epi.stats_col >= 0 || p.epi.stats != nullptr, pre,
+                       reinterpret_cast<double*>(stage), reinterpret_cast<float*>(stage + 192));
+        }
         return;
     }
 
@@ -432,9 +439,9 @@ Geometry choose_geometry(int R, int K, int V, int dtype, int cus) {
 template <int DT, int THREADS, int UNROLL>
 void launch_nt(const VerifyParams& p, int64_t grid, hipStream_t st, int nt) {
     if (nt)
-        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, true>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st, p);
+        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, true, false>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st, p);
     else
-        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, false>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st, p);
+        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, false, false>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st, p);
 }
 
 template <int DT, int THREADS>
@@ -499,6 +506,23 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     if (grid > INT32_MAX) return ASD_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
+    if (p.fused) {   // the in-kernel epilogue is instantiated for the two geometries the heuristic uses when rows >= CUs
+        const dim3 gd(static_cast<uint32_t>(grid));
+        const bool big = (g.threads == 1024 && g.unroll == 2);
+        if (!big && !(g.threads == 512 && g.unroll == 4)) return ASD_ERR_UNSUPPORTED;
+#define ASD_LAUNCH_FUSED(DT)                                                                                      \
+    do {                                                                                                          \
+        if (big) hipLaunchKernelGGL((k_verify<DT, 1024, 2, true, true>), gd, dim3(1024), 0, st, p);               \
+        else hipLaunchKernelGGL((k_verify<DT, 512, 4, true, true>), gd, dim3(512), 0, st, p);                     \
+    } while (0)
+        switch (dtype) {
+            case ASD_DTYPE_BF16: ASD_LAUNCH_FUSED(ASD_DTYPE_BF16); break;
+            case ASD_DTYPE_F16: ASD_LAUNCH_FUSED(ASD_DTYPE_F16); break;
+            default: ASD_LAUNCH_FUSED(ASD_DTYPE_F32); break;
+        }
+#undef ASD_LAUNCH_FUSED
+        return launch_status();
+    }
     switch (dtype) {
         case ASD_DTYPE_BF16: rc = launch_threads<ASD_DTYPE_BF16>(p, grid, st, g); break;
         case ASD_DTYPE_F16: rc = launch_threads<ASD_DTYPE_F16>(p, grid, st, g); break;
@@ -603,7 +627,7 @@ ASD_EXPORT int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld
     e.p_hist = p_hist; e.C = C; e.lam = lam; e.L = L; e.stage_idx = stage_idx; e.prefix = prefix_rule ? 1 : 0;
     e.theta = theta; e.B = B;
     e.score = score; e.k_star = k_star; e.stop = stop; e.thr_stop = thr_stop; e.stats = stats;
-    Geometry g{1, 0, 0, -1};   // the in-kernel epilogue lives on the one-workgroup-per-row path
+    Geometry g{1, 0, 0, 1};   // one workgroup per row; threads / tile size from the heuristic (same as the plain call)
     return launch_verify(p, dtype, workspace, workspace_bytes, stream, g);
 }
 
