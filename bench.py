@@ -402,7 +402,7 @@ def main():
                                              o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(),
                                              o.accept_bits.data_ptr(), ows.buf.data_ptr(), ows.bytes,
                                              torch.cuda.current_stream().cuda_stream)
-            for i in range(10):
+            for i in range(300):                  # same settle as the main measurement
                 overify(obufs[i % onb])
             oruns = []
             for _ in range(3):
