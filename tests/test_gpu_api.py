@@ -144,9 +144,12 @@ def test_vocab_sharded_verifier_single_rank_nccl():
     import torch.distributed as dist
     from asd_amd import distributed as D
     from tests.helpers import make_verify_case, to_device_logits
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import socket
+    with socket.socket() as sock:                       # any free port: a fixed one may be taken on a shared box
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
     try:
         case = make_verify_case(4, 8, 40000, O.DT_BF16, seed=13)
         lg = to_device_logits(case["logits"], case["dtype"]).view(4, 8, 40000)
