@@ -386,3 +386,43 @@ def test_c_abi_status_codes(K_):
     assert lib.asd_workspace_init(None, 256, st) == -1
     torch.cuda.synchronize()
     assert call() == 0                                 # the library is still healthy afterwards
+
+
+def test_fuzz_shapes_strides_dtypes_geometries(K_):
+    """60 seeded random problems: batch, draft length, vocabulary (incl. tiny and odd), row padding, dtype,
+    temperature and launch geometry all drawn at random; every one must match the oracle."""
+    import torch
+    rng = np.random.default_rng(20251004)
+    for it in range(60):
+        B = int(rng.integers(1, 70))
+        K = int(rng.choice([1, 2, 3, 4, 5, 8, 13, 16, 32, 33, 64]))
+        if B * K > 1200:
+            B = max(1, 1200 // K)
+        V = int(rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 511, 512, 513, 1000, 4096, 5003, 20000, 32768, 70001]))
+        dtype = int(rng.choice([O.DT_BF16, O.DT_F32, O.DT_F16]))
+        ld = V + int(rng.choice([0, 0, 1, 3, 8, 17]))
+        inv_t = float(np.float32(rng.choice([1.0, 1.0, 1.0 / 0.7, 0.5, 2.0])))
+        case = make_verify_case(B, K, V, dtype, seed=1000 + it, ld_row=ld, scale=float(rng.choice([1.0, 4.0, 8.0])))
+        ref = O.verify_accept(case["logits"], dtype, case["tok"], case["lp_d"], case["u"], B, K, V, ld_row=ld,
+                              n_threads=8, inv_temperature=inv_t)
+        geom = {}
+        if rng.uniform() < 0.5:
+            smax = max(1, min(64, 1024 // K))
+            geom = dict(splits=int(rng.integers(1, smax + 1)), threads=int(rng.choice([256, 512, 1024])),
+                        unroll=int(rng.choice([2, 4, 8])), nontemporal=int(rng.integers(0, 2)))
+        lg = to_device_logits(case["logits"], dtype)
+        lg3 = lg.as_strided((B, K, V), (K * ld, ld, 1))
+        ws = K_.VerifyWorkspace(B, K, V, lg.dtype)
+        r = K_.verify_accept(lg3, torch.from_numpy(case["tok"]).cuda(), torch.from_numpy(case["lp_d"]).cuda(),
+                             torch.from_numpy(case["u"]).cuda(), ws, inv_temperature=inv_t, **geom)
+        torch.cuda.synchronize()
+        got = dict(lp_t=r.lp_target.cpu().numpy(), accept=r.accept.cpu().numpy(), n_acc=r.n_acc.cpu().numpy(),
+                   bits=r.accept_bits.cpu().numpy().view(np.uint64))
+        ok = ~(ref["margin"] < 1e-4)
+        try:
+            assert_verify_matches(got, ref, check_mask=False)
+            assert np.array_equal(got["accept"][ok], ref["accept"][ok])
+            if ok.all():
+                assert np.array_equal(got["n_acc"], ref["n_acc"]) and np.array_equal(got["bits"], ref["bits"])
+        except AssertionError as e:
+            raise AssertionError(f"fuzz case {it}: B={B} K={K} V={V} ld={ld} dtype={dtype} inv_t={inv_t} geom={geom}") from e
