@@ -126,13 +126,12 @@ class SyntheticLM(nn.Module):
         # parameters are created and initialised directly on the target device in the target dtype:
         # a 72B-shape model is 145 GB and must never pass through host memory
         dev = torch.device(device) if device is not None else torch.device("cpu")
-        kw = dict(device="meta")
+        kw = dict(device="meta", dtype=dtype)          # meta + target dtype: to_empty() then allocates bf16 directly
         self.embed = nn.Embedding(shape.vocab, shape.hidden, **kw)
         self.blocks = nn.ModuleList([Block(shape, **kw) for _ in range(shape.layers)])
         self.norm = RMSNorm(shape.hidden, shape.rms_eps, **kw)
         self.lm_head = nn.Linear(shape.hidden, shape.vocab, bias=False, **kw)
         self.to_empty(device=dev)
-        self.to(dtype)
         g = torch.Generator(device=dev).manual_seed(seed)
         with torch.no_grad():
             for name, p in self.named_parameters():
