@@ -1,6 +1,7 @@
 // lse_device.hpp -- log2-domain online log-sum-exp building blocks shared by the streaming kernels
-// (verify_accept.hip, residual_sample.hip): element unpacking for bf16 / f16 / f32, the per-vector
-// accumulate, DPP wave reductions, the range-checked 16-byte buffer load and the split logarithm.
+// (verify_accept.hip, residual_sample.hip, lm_head_verify.hip): element unpacking for bf16 / f16 / f32,
+// the per-vector accumulate, DPP wave reductions, the range-checked 16-byte buffer load, the split
+// logarithm and the accept test of a finished row.
 // A partial sum is a pair (m2, s) with  sum_v exp(x_v / T) = s * 2^m2 ;  c2 = log2(e) / T.
 #pragma once
 
@@ -171,8 +172,32 @@ static __device__ __forceinline__ double log2_split(float x) {
     return static_cast<double>(e) + static_cast<double>(__builtin_amdgcn_logf(mant));
 }
 
-// lse, log-prob and acceptance test of one row from its combined (m2, s) and gathered logit.
+// ---- the accept test of one row / one sequence (DESIGN.md "accept rule") --------------
 // The sums are f64 (they mirror the oracle's structure); the two logarithms are split into an
 // exact exponent and a v_log_f32 of the mantissa, which keeps their absolute error ~1e-7 without
 // a software f64 log on the kernel's tail.
+static __device__ __forceinline__ double log_u(float u) {
+    return kLn2d * log2_split(u);  // u == 0 -> -inf (accepts), u < 0 -> NaN (rejects)
+}
+static __device__ __forceinline__ bool finish_row(float m2, float s, float x_tok, float c2, float lp_d, double lu,
+                                                  float& lp_out) {
+    // everything in the log2 domain with the SAME constant c2 the stream used, so its rounding cancels:
+    // lp = ln2 * (x_tok*c2 - (m2 + log2 s)) = log softmax(a*x)[tok] exactly for a = c2*ln2 (= 1/T to 6e-8)
+    const double l2 = static_cast<double>(m2) + log2_split(s);
+    const double lp = kLn2d * (static_cast<double>(x_tok) * static_cast<double>(c2) - l2);
+    lp_out = static_cast<float>(lp);
+    return lu <= lp - static_cast<double>(lp_d);
+}
+
+static __device__ __forceinline__ void finish_sequence(bool flag, int lane, int K, int b, int32_t* n_acc,
+                                                       uint64_t* bits) {
+    const unsigned long long bal = __ballot(flag && lane < K);
+    if (lane == 0) {
+        const unsigned long long inv = ~bal;
+        int n = inv ? __builtin_ctzll(inv) : 64;
+        n_acc[b] = n < K ? n : K;
+        if (bits) bits[b] = bal;
+    }
+}
+
 }  // namespace asd

@@ -89,30 +89,6 @@ struct VerifyParams {
     FusedParams epi;     // asd_predictor_stop's parameters (lp / n_valid unused: the kernel's own lp_t, all K)
 };
 
-__device__ __forceinline__ double log_u(float u) {
-    return kLn2d * log2_split(u);  // u == 0 -> -inf (accepts), u < 0 -> NaN (rejects)
-}
-__device__ __forceinline__ bool finish_row(float m2, float s, float x_tok, float c2, float lp_d, double lu,
-                                           float& lp_out) {
-    // everything in the log2 domain with the SAME constant c2 the stream used, so its rounding cancels:
-    // lp = ln2 * (x_tok*c2 - (m2 + log2 s)) = log softmax(a*x)[tok] exactly for a = c2*ln2 (= 1/T to 6e-8)
-    const double l2 = static_cast<double>(m2) + log2_split(s);
-    const double lp = kLn2d * (static_cast<double>(x_tok) * static_cast<double>(c2) - l2);
-    lp_out = static_cast<float>(lp);
-    return lu <= lp - static_cast<double>(lp_d);
-}
-
-__device__ __forceinline__ void finish_sequence(bool flag, int lane, int K, int b, int32_t* n_acc,
-                                                uint64_t* bits) {
-    const unsigned long long bal = __ballot(flag && lane < K);
-    if (lane == 0) {
-        const unsigned long long inv = ~bal;
-        int n = inv ? __builtin_ctzll(inv) : 64;
-        n_acc[b] = n < K ? n : K;
-        if (bits) bits[b] = bal;
-    }
-}
-
 template <int DT, int UNROLL, bool CHECK>
 __device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, uint32_t end, float c2, float& m2, float& s) {
     using E = Elem<DT>;

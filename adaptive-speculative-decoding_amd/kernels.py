@@ -154,6 +154,46 @@ def accept_from_partials(msg_all: torch.Tensor, lp_draft: torch.Tensor, u: torch
     return out
 
 
+class LmHeadVerifier:
+    """N2: lm_head projection fused with the verify pass (asd_lm_head_verify).  Holds the partials
+    workspace for one (B, K, V); `weight` is the [V, D] bf16 lm_head matrix (nn.Linear layout)."""
+
+    def __init__(self, weight: torch.Tensor, B_: int, K: int):
+        if weight.dim() != 2 or weight.dtype != torch.bfloat16 or not weight.is_cuda:
+            raise ValueError("weight must be a [V, D] bf16 CUDA tensor")
+        if weight.stride(1) != 1:
+            raise ValueError("weight rows must be contiguous")
+        self.weight = weight
+        self.B, self.K = int(B_), int(K)
+        self.V, self.D = weight.shape
+        n = int(_lib().asd_lm_head_verify_workspace_bytes(self.B, self.K, self.V))
+        self.workspace = torch.empty(max(n, 256), dtype=torch.uint8, device=weight.device)
+
+    def __call__(self, hidden: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
+                 out: Optional[VerifyResult] = None, inv_temperature: float = 1.0) -> VerifyResult:
+        """hidden [B, K, D] (or [B*K, D]) bf16: the final-norm output the lm_head would consume."""
+        Bv, K = tok.shape
+        if (Bv, K) != (self.B, self.K):
+            raise ValueError(f"verifier was sized for B={self.B}, K={self.K}, got {Bv}, {K}")
+        h2 = hidden.reshape(Bv * K, hidden.shape[-1]) if hidden.dim() == 3 else hidden
+        if h2.dtype != torch.bfloat16 or h2.shape != (Bv * K, self.D) or h2.stride(1) != 1:
+            raise ValueError("hidden must be [B*K, D] bf16 with contiguous rows")
+        dev = h2.device
+        if out is None:
+            out = VerifyResult(torch.empty((Bv, K), dtype=torch.float32, device=dev),
+                               torch.empty((Bv, K), dtype=torch.uint8, device=dev),
+                               torch.empty((Bv,), dtype=torch.int32, device=dev),
+                               torch.empty((Bv,), dtype=torch.int64, device=dev))
+        rc = _lib().asd_lm_head_verify(h2.data_ptr(), h2.stride(0) if Bv * K else self.D, self.weight.data_ptr(),
+                                       self.weight.stride(0), B.DTYPE_BF16, self.D, _dev(tok, "tok", torch.int32),
+                                       _dev(lp_draft, "lp_draft", torch.float32), _dev(u, "u", torch.float32), Bv, K,
+                                       self.V, float(inv_temperature), out.lp_target.data_ptr(), out.accept.data_ptr(),
+                                       out.n_acc.data_ptr(), out.accept_bits.data_ptr(), self.workspace.data_ptr(),
+                                       self.workspace.numel(), _stream())
+        B.check("asd_lm_head_verify", rc)
+        return out
+
+
 # ------------------------------------------------------------------------------- predictor side
 def logprob_stats(lp: torch.Tensor, n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """A7: [B,K] f32 log-probs -> [B,5] f64 (mean, std, min, q25, median), numpy semantics."""

@@ -126,6 +126,25 @@ int asd_accept_from_partials(const float* msg_all, int n_shards,
                              uint64_t* accept_bits, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * N2  lm_head projection fused with the verify pass.  The reference materialises
+ * logits = lm_head(hidden) and then gathers log-probs from them
+ * (src/training/generate_training_data.py:128-136 via model.generate(output_scores=True));
+ * here  logits[b,k,v] = sum_d hidden[b,k,d] * weight[v,d]  live only in MFMA accumulators (f32)
+ * and are reduced on chip to the same (m2, s, g) partials as asd_lse_partial, one per 128-column
+ * vocabulary block, then combined and tested exactly like asd_accept_from_partials.
+ * hidden [B*K][ld_h], weight [V][ld_w] (the nn.Linear / HF lm_head layout), both bf16 (dtype =
+ * ASD_DTYPE_BF16; others: ASD_ERR_UNSUPPORTED), D % 32 == 0, ld % 8 == 0, 16-byte aligned bases.
+ * The log-sum-exp is over UNROUNDED f32 logits, i.e. closer to the exact product than the
+ * bf16-materialised path: results agree with asd_verify_accept on bf16(hidden @ weight.T) to the
+ * bf16 rounding of the logits, not bit for bit (tests/test_gpu_lm_head.py states the tolerance).
+ * Workspace: asd_lm_head_verify_workspace_bytes(B, K, V), no initialisation needed. */
+size_t asd_lm_head_verify_workspace_bytes(int B, int K, int V);
+int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* weight, int64_t ld_w, int dtype, int D,
+                       const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
+                       float inv_temperature, float* lp_target, uint8_t* accept, int32_t* n_acc,
+                       uint64_t* accept_bits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A7  log-prob statistics: features [5..9] of extract_features,
  * src/training/generate_training_data.py:166-175 -- np.mean, np.std (population), np.min,
  * np.percentile(.,25) (linear interpolation), np.median, all in float64 like numpy.

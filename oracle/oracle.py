@@ -177,6 +177,25 @@ def py_verify_accept(logits_f32: np.ndarray, tok, lp_d, u):
     return lp, acc.astype(np.uint8), n_acc
 
 
+def lm_head_verify(hidden_bits: np.ndarray, weight_bits: np.ndarray, tok, lp_d, u, B: int, K: int,
+                   inv_temperature: float = 1.0):
+    """N2 oracle: logits = hidden @ weight.T in f64 from the bf16 bit patterns (hidden [B*K, D],
+    weight [V, D], both uint16), then the A5 rule on x * inv_temperature in f64.  The f32
+    inv_temperature is used exactly as the C oracle does.  Parity unpinned (A5 has no reference
+    symbol).  Returns dict(lp_t64, accept, n_acc, bits, margin, logits64)."""
+    h = bf16_bits_to_f32(np.asarray(hidden_bits)).astype(np.float64)
+    w = bf16_bits_to_f32(np.asarray(weight_bits)).astype(np.float64)
+    V = w.shape[0]
+    x = h @ w.T
+    a = float(np.float32(inv_temperature))
+    lp, acc, n_acc = py_verify_accept((x * a).reshape(B, K, V), tok, lp_d, u)
+    bits = np.array([sum(int(f) << k for k, f in enumerate(row)) for row in acc], dtype=np.uint64)
+    with np.errstate(all="ignore"):
+        uu = np.asarray(u, dtype=np.float32).reshape(B, K).astype(np.float64)
+        margin = np.abs(np.log(uu) - (lp - np.asarray(lp_d, dtype=np.float32).reshape(B, K).astype(np.float64)))
+    return dict(lp_t64=lp, accept=acc, n_acc=n_acc, bits=bits, margin=margin, logits64=x.reshape(B, K, V))
+
+
 # ----------------------------------------------------------------------------- A7
 def logprob_stats(lp, n_valid=None, K: Optional[int] = None) -> np.ndarray:
     lib = _load()

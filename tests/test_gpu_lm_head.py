@@ -1,0 +1,184 @@
+"""N2: asd_lm_head_verify -- the lm_head GEMM fused with the verify pass -- against
+the f64 oracle (oracle.lm_head_verify: f64 product of the bf16 operands, then the A5 rule).
+
+Tolerance: the kernel accumulates bf16 x bf16 products in f32 MFMA accumulators over D terms, so
+its logits carry ~sqrt(D) * 2^-24 * |x| of rounding that the streaming kernel (which reads given
+logits) does not have.  LMH_ATOL = 2e-4 on the log-prob covers D = 8192 at |x| <~ 30; the accept
+mask / n_acc / ballot word must be identical on inputs whose decision margin is >= 10 * LMH_ATOL.
+Parity unpinned in the sense of DESIGN.md: A5 has no reference symbol."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LMH_ATOL = 2e-4
+LMH_MARGIN = 2e-3
+
+
+def make_case(B, K, D, V, seed=0, scale=3.0, ld_h=None, ld_w=None, inv_t=1.0):
+    rng = np.random.default_rng(seed)
+    M = B * K
+    hb = O.f32_to_bf16_bits(rng.standard_normal((M, D), dtype=np.float32))
+    wb = O.f32_to_bf16_bits(rng.standard_normal((V, D), dtype=np.float32) * np.float32(scale / np.sqrt(D)))
+    x = O.bf16_bits_to_f32(hb).astype(np.float64) @ O.bf16_bits_to_f32(wb).astype(np.float64).T
+    amax = x.argmax(axis=1)
+    tok = np.where(rng.uniform(size=M) < 0.7, amax, rng.integers(0, V, M)).astype(np.int32).reshape(B, K)
+    base = O.lm_head_verify(hb, wb, tok, np.zeros((B, K), np.float32), np.full((B, K), 0.5, np.float32), B, K, inv_t)
+    lp_t = base["lp_t64"]
+    lp_d = np.minimum(lp_t + rng.normal(0, 0.5, (B, K)), 0.0).astype(np.float32)
+    u = rng.uniform(0, 1, (B, K)).astype(np.float32)
+    for _ in range(100):
+        with np.errstate(divide="ignore"):
+            m = np.abs(np.log(u.astype(np.float64)) - (lp_t - lp_d.astype(np.float64)))
+        bad = ~(m >= LMH_MARGIN)
+        if not bad.any():
+            break
+        u[bad] = rng.uniform(0, 1, int(bad.sum())).astype(np.float32)
+    ref = O.lm_head_verify(hb, wb, tok, lp_d, u, B, K, inv_t)
+    return dict(B=B, K=K, D=D, V=V, hb=hb, wb=wb, tok=tok, lp_d=lp_d, u=u, ref=ref, ld_h=ld_h or D, ld_w=ld_w or D,
+                inv_t=inv_t)
+
+
+def bf16_dev(bits, ld=None):
+    import torch
+
+    t = torch.from_numpy(bits.view(np.int16)).cuda().view(torch.bfloat16)
+    if ld is None or ld == bits.shape[1]:
+        return t
+    pad = torch.full((bits.shape[0], ld), 1.0e4, dtype=torch.bfloat16, device="cuda")   # poisoned padding
+    pad[:, :bits.shape[1]] = t
+    return pad[:, :bits.shape[1]]
+
+
+def run_gpu(case):
+    import torch
+
+    from asd_amd import kernels as Kn
+
+    w = bf16_dev(case["wb"], case["ld_w"])
+    h = bf16_dev(case["hb"], case["ld_h"])
+    ver = Kn.LmHeadVerifier(w, case["B"], case["K"])
+    r = ver(h, torch.from_numpy(case["tok"]).cuda(), torch.from_numpy(case["lp_d"]).cuda(),
+            torch.from_numpy(case["u"]).cuda(), inv_temperature=case["inv_t"])
+    torch.cuda.synchronize()
+    return dict(lp_t=r.lp_target.cpu().numpy(), accept=r.accept.cpu().numpy(), n_acc=r.n_acc.cpu().numpy(),
+                bits=r.accept_bits.cpu().numpy().view(np.uint64))
+
+
+def check(got, ref):
+    a, b = got["lp_t"].astype(np.float64), ref["lp_t64"]
+    fin = np.isfinite(b)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=0, atol=LMH_ATOL)
+    assert np.array_equal(a[~fin], b[~fin])
+    assert np.array_equal(got["accept"], ref["accept"])
+    assert np.array_equal(got["n_acc"], ref["n_acc"])
+    assert np.array_equal(got["bits"], ref["bits"])
+
+
+@pytest.mark.parametrize("B,K,D,V", [
+    (1, 1, 32, 5),           # one row, one column block, mostly padding
+    (3, 5, 64, 300),         # ragged rows and a ragged last column block
+    (5, 8, 256, 1000),
+    (32, 8, 512, 4173),      # the full 256-row tile
+    (40, 8, 128, 640),       # two row blocks
+    (9, 33, 96, 129),        # K > 32, 297 rows, one column in the last block
+    (2, 64, 160, 257),       # K = ASD_MAX_DRAFT_LEN
+])
+def test_lm_head_verify_matches_oracle(B, K, D, V):
+    case = make_case(B, K, D, V, seed=B * 1000 + K)
+    check(run_gpu(case), case["ref"])
+
+
+def test_lm_head_verify_strided_operands_and_temperature():
+    case = make_case(4, 7, 128, 777, seed=5, ld_h=136, ld_w=200, inv_t=1.0 / 0.7)
+    check(run_gpu(case), case["ref"])
+
+
+def test_lm_head_verify_token_outside_vocabulary_is_rejected():
+    case = make_case(2, 4, 64, 200, seed=9)
+    case["tok"][0, 1] = -1
+    case["tok"][1, 2] = 200
+    case["ref"] = O.lm_head_verify(case["hb"], case["wb"], case["tok"], case["lp_d"], case["u"], 2, 4)
+    got = run_gpu(case)
+    assert got["lp_t"][0, 1] == -np.inf and got["lp_t"][1, 2] == -np.inf
+    assert got["accept"][0, 1] == 0 and got["accept"][1, 2] == 0
+    check(got, case["ref"])
+
+
+def test_lm_head_verify_deep_reduction_error_budget():
+    """D = 8192 (the 72B lm_head depth) at a reduced vocabulary: the f32 accumulation stays inside LMH_ATOL."""
+    case = make_case(8, 8, 8192, 1536, seed=11, scale=4.0)
+    got = run_gpu(case)
+    err = np.abs(got["lp_t"].astype(np.float64) - case["ref"]["lp_t64"]).max()
+    print(f"max |lp - oracle| at D=8192: {err:.3e}")
+    check(got, case["ref"])
+
+
+def test_lm_head_verify_agrees_with_materialised_logits_at_full_size():
+    """BASELINE configs[1] shape with the 7B lm_head (D = 3584, V = 152064): the fused call against
+    asd_verify_accept on the f32 logits torch materialises from the same operands."""
+    import torch
+
+    from asd_amd import kernels as Kn
+
+    B, K, D, V = 32, 8, 3584, 152064
+    g = torch.Generator(device="cuda").manual_seed(3)
+    h = torch.randn((B * K, D), device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn((V, D), device="cuda", generator=g) * (3.0 / D ** 0.5)).to(torch.bfloat16)
+    logits = (h.float() @ w.float().T).reshape(B, K, V)
+    tok = logits.argmax(-1).to(torch.int32)
+    tok[:, 1::3] = torch.randint(0, V, tok[:, 1::3].shape, device="cuda", dtype=torch.int32)
+    lp_d = -torch.rand((B, K), device="cuda") * 3
+    u = torch.rand((B, K), device="cuda")
+    ws = Kn.VerifyWorkspace(B, K, V, torch.float32)
+    two = Kn.verify_accept(logits, tok, lp_d, u, ws)
+    one = Kn.LmHeadVerifier(w, B, K)(h, tok, lp_d, u)
+    torch.cuda.synchronize()
+    a, b = one.lp_target.double(), two.lp_target.double()
+    assert torch.isfinite(b).all()
+    assert (a - b).abs().max().item() <= LMH_ATOL
+    margin = (torch.log(u.double()) - (b - lp_d.double())).abs()
+    safe = margin >= LMH_MARGIN
+    assert torch.equal(one.accept[safe], two.accept[safe])
+    assert safe.float().mean().item() > 0.9
+
+
+def test_lm_head_verify_status_codes():
+    import torch
+
+    from asd_amd import _binding as Bd
+
+    lib = Bd.load_library()
+    B, K, D, V = 2, 3, 64, 100
+    h = torch.zeros((B * K, D), dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros((V, D), dtype=torch.bfloat16, device="cuda")
+    tok = torch.zeros((B, K), dtype=torch.int32, device="cuda")
+    f = torch.zeros((B, K), dtype=torch.float32, device="cuda")
+    acc = torch.zeros((B, K), dtype=torch.uint8, device="cuda")
+    n = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    nbytes = lib.asd_lm_head_verify_workspace_bytes(B, K, V)
+    assert nbytes >= 1 * B * K * 12 and nbytes % 256 == 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+
+    def call(**kw):
+        a = dict(h=h.data_ptr(), ld_h=D, w=w.data_ptr(), ld_w=D, dtype=Bd.DTYPE_BF16, D=D, B=B, K=K, V=V, inv_t=1.0,
+                 ws=ws.data_ptr(), ws_bytes=nbytes)
+        a.update(kw)
+        return lib.asd_lm_head_verify(a["h"], a["ld_h"], a["w"], a["ld_w"], a["dtype"], a["D"], tok.data_ptr(),
+                                      f.data_ptr(), f.data_ptr(), a["B"], a["K"], a["V"], a["inv_t"], f.data_ptr(),
+                                      acc.data_ptr(), n.data_ptr(), None, a["ws"], a["ws_bytes"], None)
+
+    assert call() == 0
+    assert call(B=0) == 0
+    assert call(dtype=Bd.DTYPE_F16) == -2
+    assert call(D=48, ld_h=48, ld_w=48) == -2
+    assert call(K=65) == -2
+    assert call(ld_h=D - 8) == -1
+    assert call(inv_t=0.0) == -1
+    assert call(h=None) == -1
+    assert call(ld_w=D + 4) == -5
+    assert call(h=h.data_ptr() + 2) == -5
+    assert call(ws_bytes=nbytes - 256) == -3
+    torch.cuda.synchronize()
