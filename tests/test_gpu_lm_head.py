@@ -78,13 +78,14 @@ def check(got, ref):
 
 
 @pytest.mark.parametrize("B,K,D,V", [
-    (1, 1, 32, 5),           # one row, one column block, mostly padding
+    (1, 1, 64, 5),           # one row, one column block, mostly padding
     (3, 5, 64, 300),         # ragged rows and a ragged last column block
     (5, 8, 256, 1000),
     (32, 8, 512, 4173),      # the full 256-row tile
     (40, 8, 128, 640),       # two row blocks
-    (9, 33, 96, 129),        # K > 32, 297 rows, one column in the last block
-    (2, 64, 160, 257),       # K = ASD_MAX_DRAFT_LEN
+    (9, 33, 192, 129),       # K > 32, 297 rows, one column in the last block, odd superstage count
+    (2, 64, 320, 257),       # K = ASD_MAX_DRAFT_LEN
+    (32, 8, 128, 66000),     # wide (256-column) blocks for whole rounds of CUs + narrow blocks for the rest
 ])
 def test_lm_head_verify_matches_oracle(B, K, D, V):
     case = make_case(B, K, D, V, seed=B * 1000 + K)
@@ -174,6 +175,7 @@ def test_lm_head_verify_status_codes():
     assert call(B=0) == 0
     assert call(dtype=Bd.DTYPE_F16) == -2
     assert call(D=48, ld_h=48, ld_w=48) == -2
+    assert call(D=96, ld_h=96, ld_w=96) == -2      # whole 64-column superstages only
     assert call(K=65) == -2
     assert call(ld_h=D - 8) == -1
     assert call(inv_t=0.0) == -1
