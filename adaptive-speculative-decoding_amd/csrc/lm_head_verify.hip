@@ -3,12 +3,12 @@
 //
 //   logits[m][v] = sum_k hidden[m][k] * weight[v][k]          (bf16 x bf16 -> f32, m = b*K + k)
 //
-// k_lm_head_tile<NT>: one workgroup (8 waves, one per CU) owns 32*NT vocabulary columns x up to 256 rows;
-// wave w owns rows 32w .. 32w+31 and keeps its 32 x 32*NT logits in MFMA accumulators
+// k_lm_head_tile<NTW>: one workgroup (8 waves as 4 x 2, one workgroup per CU) owns 64*NTW vocabulary
+// columns x up to 256 rows; a wave keeps its 64 rows x 32*NTW columns of logits in MFMA accumulators
 // (v_mfma_f32_32x32x16_bf16 with the WEIGHT tile as the A operand, so a lane holds 16 vocabulary entries
 // of ONE row and the row reduction is lane-local).  At the end the accumulators are folded into the
 // log2-domain partial (m2, s) of lse_device.hpp, logit[tok] is gathered where the block owns it, and the
-// (m2, s, g) triple asd_lse_partial emits for a vocabulary shard is written per 128-column unit.
+// (m2, s, g) triple asd_lse_partial emits for a vocabulary shard is written per 64-column unit.
 // k_accept_from_blocks merges the units of every row and applies the accept rule (finish_row /
 // finish_sequence: the code the streaming kernel ends in).
 //
@@ -18,7 +18,7 @@
 //   weights  nt, 3-slot LDS ring: two superstages in flight while one is multiplied;
 //   hidden   (L2 / MALL hits) 2-slot ring: one superstage in flight.
 // (64-byte pieces per row and instruction -- a 32-column stage -- moved ~20 % fewer bytes per second.)
-// With NT = 8 the rings take 3 x 32 + 2 x 32 = 160 KiB: all of a CU's LDS.
+// With 256-column blocks the rings take 3 x 32 + 2 x 32 = 160 KiB: all of a CU's LDS.
 // MFMA k-slot (ks, h, j) of a superstage is reduction column 32h + 8ks + j for BOTH operands (any
 // bijection works as long as A and B agree), so a lane's fragment is one 16-byte segment 4h + ks of its
 // row; the LDS image is swizzled (segment ^ (row >> 1) & 7, on the DMA source address and on the fragment
@@ -43,7 +43,6 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 constexpr int kBM = 256;        // rows (draft positions) per workgroup: 4 wave rows x 64
-constexpr int kUnit = 64;       // columns behind one (m2, s, g) triple
 constexpr int kSuper = 64;      // reduction columns per superstage = one 128-byte line per row
 constexpr int kThreads = 512;
 constexpr int kWRing = 3;       // LDS slots of one weight superstage each (two in flight, one multiplied)
@@ -57,9 +56,10 @@ struct LmHeadParams {
     int D, M, V;
     const int32_t* tok;
     float c2;
-    float* msg;          // [n_units][M][3]
+    float* msg;          // [blocks of both launches][M][3]
     int m_blocks;
-    int col0;            // first vocabulary column of this launch (multiple of kUnit)
+    int col0;            // first vocabulary column of this launch
+    int unit0;           // index of this launch's first block in msg (one triple per row and block)
 };
 
 template <int PENDING>
@@ -158,11 +158,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 1 < 4) read_frags(ks + 1);
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);   // MFMA issue ahead of the other wave's reads / DMA issue: -10 % (7B head)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], hf[ks & 1][mt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -197,26 +199,26 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         compute(S);
 #endif
     }
-    if (!wave_works) return;
-
     // ---- epilogue: D[vocab row][m column]; lane (r, h) holds row m and, per 32-column tile, the 16
-    // vocabulary ids  n = tile + (i & 3) + 8 * (i >> 2) + 4 * h.  One (m2, s, g) triple per row and 64 columns.
+    // vocabulary ids  n = tile + (i & 3) + 8 * (i >> 2) + 4 * h.  A wave folds its 32 * NTW columns per row,
+    // the two wave columns meet in LDS (free now: every DMA was retired by the last wait), and the block
+    // writes ONE (m2, s, g) triple per row.
+    float* const meet = reinterpret_cast<float*>(lds);   // [256 rows][3]
+    __syncthreads();                                      // the last superstage's fragment reads are done
+    float tm2[2], ts[2], tg[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + 64 * wm + 32 * mt + r;
-        const int tk = m < p.M ? p.tok[m] : -1;
+        const int tk = (wave_works && m < p.M) ? p.tok[m] : -1;
+        float m2 = kSentinel, s = 0.0f, g = -INFINITY;
+        if (wave_works) {
 #pragma unroll
-        for (int su = 0; su < NTW / 2; ++su) {
-            const int u0 = n0 + 32 * NTW * wn + kUnit * su;
-            if (u0 >= p.V) break;   // wave-uniform
-            float m2 = kSentinel, s = 0.0f, g = -INFINITY;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) {
                 float x[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int n = u0 + 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const float v = n < p.V ? acc[mt][2 * su + nt][i] : -INFINITY;   // padded weight rows are not vocabulary
+                    const int n = n0 + 32 * NTW * wn + 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const float v = n < p.V ? acc[mt][nt][i] : -INFINITY;   // padded weight rows are not vocabulary
                     if (n == tk) g = v;
                     x[i] = v;
                 }
@@ -226,33 +228,49 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
                 accum8(lo, p.c2, m2, s);
                 accum8(hi, p.c2, m2, s);
             }
-            // the row's other 32 columns sit in lane r ^ 32
-            const float m2o = __shfl_xor(m2, 32, 64);
-            const float so = __shfl_xor(s, 32, 64);
-            const float go = __shfl_xor(g, 32, 64);
-            ms_merge(m2, s, m2o, so);
-            g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));   // a NaN logit must not be dropped by max
-            if (h == 0 && m < p.M) {
-                float* out = p.msg + (static_cast<int64_t>(u0 / kUnit) * p.M + m) * 3;
-                out[0] = m2;
-                out[1] = s;
-                out[2] = g;
-            }
         }
+        // the row's other columns of these tiles sit in lane r ^ 32
+        const float m2o = __shfl_xor(m2, 32, 64);
+        const float so = __shfl_xor(s, 32, 64);
+        const float go = __shfl_xor(g, 32, 64);
+        ms_merge(m2, s, m2o, so);
+        g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));   // a NaN logit must not be dropped by max
+        tm2[mt] = m2; ts[mt] = s; tg[mt] = g;
+        if (wn == 1 && h == 0) {
+            float* q = meet + (64 * wm + 32 * mt + r) * 3;
+            q[0] = m2; q[1] = s; q[2] = g;
+        }
+    }
+    __syncthreads();
+    if (wn != 0 || h != 0) return;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + 64 * wm + 32 * mt + r;
+        if (m >= p.M) continue;
+        const float* q = meet + (64 * wm + 32 * mt + r) * 3;
+        float m2 = tm2[mt], s = ts[mt], g = tg[mt];
+        ms_merge(m2, s, q[0], q[1]);
+        const float go = q[2];
+        g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));
+        float* out = p.msg + (static_cast<int64_t>(p.unit0 + nb) * p.M + m) * 3;
+        out[0] = m2;
+        out[1] = s;
+        out[2] = g;
     }
 }
 
-// merge the per-block triples of every row of sequence b, then the accept rule.  4 waves; wave w
-// takes draft positions w, w + 4, ...; its lanes stride over the blocks (fixed order: deterministic).
-__global__ __launch_bounds__(256) void k_accept_from_blocks(const float* msg, int n_blocks, const float* lp_d,
+// merge the per-block triples of every row of sequence b, then the accept rule.  Up to 16 waves; wave w
+// takes draft positions w, w + waves, ...; its lanes stride over the blocks (fixed order: deterministic).
+__global__ __launch_bounds__(1024) void k_accept_from_blocks(const float* msg, int n_blocks, const float* lp_d,
                                                             const float* u, int B, int K, float c2, float* lp_t,
                                                             uint8_t* accept, int32_t* n_acc, uint64_t* bits) {
     __shared__ float red[ASD_MAX_DRAFT_LEN][3];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
     const int64_t M = static_cast<int64_t>(B) * K;
-    for (int k = w; k < K; k += 4) {
+    for (int k = w; k < K; k += waves) {
         const int64_t row = static_cast<int64_t>(b) * K + k;
         float m2 = kSentinel, s = 0.0f, g = -INFINITY;
         bool gnan = false;
@@ -285,7 +303,8 @@ __global__ __launch_bounds__(256) void k_accept_from_blocks(const float* msg, in
     finish_sequence(flag, lane, K, b, n_acc, bits);
 }
 
-inline int n_units_for(int V) { return (V + kUnit - 1) / kUnit; }
+// upper bound of the column blocks of one call (all of them narrow)
+inline int max_blocks_for(int V) { return (V + 127) / 128; }
 
 }  // namespace
 }  // namespace asd
@@ -294,7 +313,7 @@ using namespace asd;
 
 ASD_EXPORT size_t asd_lm_head_verify_workspace_bytes(int B, int K, int V) {
     if (B <= 0 || K <= 0 || V <= 0) return 0;
-    return round_up(static_cast<size_t>(n_units_for(V)) * static_cast<size_t>(B) * K * 3 * sizeof(float), 256);
+    return round_up(static_cast<size_t>(max_blocks_for(V)) * static_cast<size_t>(B) * K * 3 * sizeof(float), 256);
 }
 
 ASD_EXPORT int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* weight, int64_t ld_w, int dtype, int D,
@@ -313,9 +332,8 @@ ASD_EXPORT int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* 
     if (!aligned_to(workspace, 16)) return ASD_ERR_ALIGNMENT;
 
     const int64_t M = static_cast<int64_t>(B) * K;
-    const int n_units = n_units_for(V);
     const int64_t m_blocks = (M + kBM - 1) / kBM;
-    if (M >= (1ll << 31) || m_blocks * n_units >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
+    if (M >= (1ll << 31) || m_blocks * max_blocks_for(V) >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
     // 256-column blocks while they fill whole rounds of the CUs, 128-column blocks for the rest
     const int64_t cus = current_device_cus();
     const int64_t wide = (static_cast<int64_t>(V / 256) * m_blocks / cus) * cus / m_blocks;
@@ -330,13 +348,15 @@ ASD_EXPORT int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (wide > 0) {
         p.col0 = 0;
+        p.unit0 = 0;
         hipLaunchKernelGGL(k_lm_head_tile<4>, dim3(static_cast<unsigned>(wide * m_blocks)), dim3(kThreads), 0, st, p);
     }
     if (narrow > 0) {
         p.col0 = tail_col;
+        p.unit0 = static_cast<int>(wide);
         hipLaunchKernelGGL(k_lm_head_tile<2>, dim3(static_cast<unsigned>(narrow * m_blocks)), dim3(kThreads), 0, st, p);
     }
-    hipLaunchKernelGGL(k_accept_from_blocks, dim3(B), dim3(256), 0, st, p.msg, n_units, lp_draft, u, B, K, p.c2,
+    hipLaunchKernelGGL(k_accept_from_blocks, dim3(B), dim3(64 * (K < 16 ? K : 16)), 0, st, p.msg, static_cast<int>(wide + narrow), lp_draft, u, B, K, p.c2,
                        lp_target, accept, n_acc, accept_bits);
     return launch_status();
 }
