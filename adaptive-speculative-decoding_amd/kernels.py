@@ -87,9 +87,11 @@ def _logits_2d(logits: torch.Tensor, Bv: int, K: int) -> Tuple[int, int, int]:
     if logits.dim() == 3:
         if logits.shape[0] != Bv or logits.shape[1] != K:
             raise ValueError("logits must be [B,K,V]")
-        if logits.stride(2) != 1 or logits.stride(0) != K * logits.stride(1):
+        # the stride of a size-1 dimension is arbitrary (a [1, 64, V] slice of [1, 70, V] keeps stride(0) = 70 V)
+        if logits.stride(2) != 1 or (Bv > 1 and logits.stride(0) != K * logits.stride(1)):
             raise ValueError("logits rows must be unit-stride in V and evenly spaced over (b,k)")
-        return logits.shape[2], logits.stride(1), logits.data_ptr()
+        ld = logits.stride(1) if K > 1 else (logits.stride(0) if Bv > 1 else logits.shape[2])
+        return logits.shape[2], ld, logits.data_ptr()
     if logits.dim() == 2:
         if logits.shape[0] != Bv * K or logits.stride(1) != 1:
             raise ValueError("2-D logits must be [B*K, V] with unit stride in V")
@@ -184,7 +186,7 @@ class LmHeadVerifier:
                                torch.empty((Bv, K), dtype=torch.uint8, device=dev),
                                torch.empty((Bv,), dtype=torch.int32, device=dev),
                                torch.empty((Bv,), dtype=torch.int64, device=dev))
-        rc = _lib().asd_lm_head_verify(h2.data_ptr(), h2.stride(0) if Bv * K else self.D, self.weight.data_ptr(),
+        rc = _lib().asd_lm_head_verify(h2.data_ptr(), h2.stride(0) if Bv * K > 1 else self.D, self.weight.data_ptr(),
                                        self.weight.stride(0), B.DTYPE_BF16, self.D, _dev(tok, "tok", torch.int32),
                                        _dev(lp_draft, "lp_draft", torch.float32), _dev(u, "u", torch.float32), Bv, K,
                                        self.V, float(inv_temperature), out.lp_target.data_ptr(), out.accept.data_ptr(),

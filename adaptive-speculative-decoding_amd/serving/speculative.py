@@ -61,6 +61,7 @@ class SpeculativeVerifier:
         self.sampler = K.ResidualSampler(batch, vocab, logits_dtype, self.device)   # commit step (asd_residual_sample)
         self.in_dim = self.hidden = 0
         self.packed = None
+        self._lm_head = None              # (key, kernels.LmHeadVerifier) of the last verify_hidden call
         if predictor is not None:
             self.set_predictor(predictor)
 
@@ -77,6 +78,32 @@ class SpeculativeVerifier:
         """`logits` are RAW target logits: 1/temperature is applied inside the kernel (self.inv_temperature)."""
         return K.verify_accept(logits, tok, lp_draft, u, self.ws, out, inv_temperature=self.inv_temperature)
 
+    def verify_hidden(self, hidden: torch.Tensor, lm_head_weight: torch.Tensor, tok: torch.Tensor,
+                      lp_draft: torch.Tensor, u: torch.Tensor, out: Optional[K.VerifyResult] = None,
+                      logit_scale: float = 1.0) -> K.VerifyResult:
+        """N2: verify from the target's final hidden states [B, K, D] and its lm_head matrix [V, D] (bf16);
+        the [B, K, V] logits stay in MFMA accumulators (asd_lm_head_verify).  `logit_scale` multiplies the
+        logits like SyntheticLM.logit_scale; it rides on the temperature constant."""
+        key = (lm_head_weight.data_ptr(), tok.shape[0], tok.shape[1])
+        if self._lm_head is None or self._lm_head[0] != key:
+            self._lm_head = (key, K.LmHeadVerifier(lm_head_weight, tok.shape[0], tok.shape[1]))
+        return self._lm_head[1](hidden, tok, lp_draft, u, out, inv_temperature=self.inv_temperature * logit_scale)
+
+    def step_hidden(self, hidden: torch.Tensor, lm_head_weight: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor,
+                    u: torch.Tensor, feat: Optional[torch.Tensor] = None, stage_idx: int = 0,
+                    out: Optional[K.VerifyResult] = None, logit_scale: float = 1.0) -> StepResult:
+        """`step` for a target tier that hands over hidden states instead of logits."""
+        v = self.verify_hidden(hidden, lm_head_weight, tok, lp_draft, u, out, logit_scale)
+        return StepResult(v, self._stop(v, tok, feat, stage_idx))
+
+    def _stop(self, v: K.VerifyResult, tok: torch.Tensor, feat: Optional[torch.Tensor], stage_idx: int):
+        if self.packed is None or feat is None:
+            return None
+        return K.predictor_stop(feat, self.packed, self.in_dim, self.hidden, stage_idx=stage_idx, L=self.L,
+                                lp=v.lp_target, stats_col=self.stats_col, risk_adjustment=self.risk, n_obs=self.n_obs,
+                                alpha=self.alpha, beta=self.beta, p_hist=self.p_hist[: tok.shape[0]], Cc=self.costs,
+                                lam=self.lam, prefix_rule=self.prefix)
+
     def step(self, logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
              feat: Optional[torch.Tensor] = None, stage_idx: int = 0, out: Optional[K.VerifyResult] = None) -> StepResult:
         """One verify + stop decision for the whole batch: two launches (one with fused=True), nothing synchronises."""
@@ -88,13 +115,7 @@ class SpeculativeVerifier:
                                          prefix_rule=self.prefix, out=out)
             return StepResult(v, s)
         v = self.verify(logits, tok, lp_draft, u, out)
-        s = None
-        if self.packed is not None and feat is not None:
-            s = K.predictor_stop(feat, self.packed, self.in_dim, self.hidden, stage_idx=stage_idx, L=self.L,
-                                 lp=v.lp_target, stats_col=self.stats_col, risk_adjustment=self.risk, n_obs=self.n_obs,
-                                 alpha=self.alpha, beta=self.beta, p_hist=self.p_hist[: tok.shape[0]], Cc=self.costs,
-                                 lam=self.lam, prefix_rule=self.prefix)
-        return StepResult(v, s)
+        return StepResult(v, self._stop(v, tok, feat, stage_idx))
 
 
 # ------------------------------------------------------------------------------------ plumbing

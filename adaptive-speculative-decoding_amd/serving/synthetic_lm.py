@@ -162,12 +162,18 @@ class SyntheticLM(nn.Module):
         self._len = length
 
     @torch.no_grad()
-    def forward(self, ids: torch.Tensor) -> torch.Tensor:
-        """ids: [B, T] NEW tokens (positions cached_len ... cached_len+T-1) -> logits [B, T, V]."""
+    def forward(self, ids: torch.Tensor, return_hidden: bool = False) -> torch.Tensor:
+        """ids: [B, T] NEW tokens (positions cached_len ... cached_len+T-1) -> logits [B, T, V].
+
+        return_hidden=True stops before the lm_head and returns the final-norm states [B, T, D]: the input
+        of asd_lm_head_verify (logits = hidden @ lm_head.weight.T * logit_scale are then never materialised)."""
         B, T = ids.shape
         pos = torch.arange(self._len, self._len + T, device=ids.device)
         x = self.embed(ids)
         for i, blk in enumerate(self.blocks):
             x, self._cache[i] = blk(x, pos, self._cache[i])
         self._len += T
-        return self.lm_head(self.norm(x)) * self.logit_scale
+        x = self.norm(x)
+        if return_hidden:
+            return x
+        return self.lm_head(x) * self.logit_scale

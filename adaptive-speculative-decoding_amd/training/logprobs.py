@@ -43,6 +43,30 @@ def token_logprobs(scores, token_ids) -> np.ndarray:
     return out[0] if squeeze else out
 
 
+def token_logprobs_from_hidden(hidden, lm_head_weight, token_ids, inv_temperature: float = 1.0):
+    """token_logprobs without the scores: log softmax(hidden @ lm_head_weight.T)[token] straight from the
+    final hidden states (asd_lm_head_verify), so [T, V] scores are never stored.
+
+    hidden: [T, D] or [B, T, D] bf16 CUDA tensor; lm_head_weight: [V, D] bf16 CUDA tensor (nn.Linear layout);
+    token_ids: [T] or [B, T].  Returns a float32 CUDA tensor of log-probs of the leading shape."""
+    import torch
+
+    from .. import kernels as K
+
+    squeeze = hidden.dim() == 2
+    h3 = hidden.unsqueeze(0) if squeeze else hidden
+    B, T, _ = h3.shape
+    tok = torch.as_tensor(token_ids, device=h3.device).to(torch.int32).reshape(B, T)
+    out = torch.empty((B, T), dtype=torch.float32, device=h3.device)
+    for s in range(0, T, 64):                              # ASD_MAX_DRAFT_LEN positions per sequence per launch
+        e = min(T, s + 64)
+        zeros = torch.zeros((B, e - s), dtype=torch.float32, device=h3.device)
+        ver = K.LmHeadVerifier(lm_head_weight, B, e - s)
+        r = ver(h3[:, s:e].contiguous(), tok[:, s:e].contiguous(), zeros, zeros + 1.0, inv_temperature=inv_temperature)
+        out[:, s:e] = r.lp_target
+    return out[0] if squeeze else out
+
+
 def _text_features(prompt: str, output: str, metadata: Dict, stage_id: int) -> List[float]:
     pw, ow = prompt.split(), output.split()
     f: List[float] = [len(pw), len(prompt), len(ow), len(output), len(ow) / max(len(pw), 1)]

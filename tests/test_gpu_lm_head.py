@@ -184,3 +184,59 @@ def test_lm_head_verify_status_codes():
     assert call(h=h.data_ptr() + 2) == -5
     assert call(ws_bytes=nbytes - 256) == -3
     torch.cuda.synchronize()
+
+
+def test_model_tier_hands_over_hidden_states():
+    """SyntheticLM(return_hidden) + SpeculativeVerifier.step_hidden against the f64 oracle on the same
+    hidden states / lm_head matrix, and against the logits path (which rounds the logits to bf16 first:
+    agreement there is to that rounding only)."""
+    import torch
+
+    from asd_amd.minimal_adaptive_decoder import MinimalQualityPredictor
+    from asd_amd.serving import synthetic_lm as SL
+    from asd_amd.serving.speculative import SpeculativeVerifier
+
+    B, K, V = 4, 6, 1500
+    lm = SL.SyntheticLM(SL.tiny(vocab=V, hidden=128), device="cuda", seed=3, logit_scale=2.0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    ids = torch.randint(0, V, (B, K), device="cuda", generator=g)
+    hidden = lm(ids, return_hidden=True)
+    lm.reset()
+    logits = lm(ids)
+    tok = logits.argmax(-1).to(torch.int32)
+    tok[:, 1::2] = torch.randint(0, V, tok[:, 1::2].shape, device="cuda", generator=g, dtype=torch.int32)
+    lp_d = -torch.rand((B, K), device="cuda", generator=g) * 2
+    u = torch.rand((B, K), device="cuda", generator=g)
+    torch.manual_seed(0)
+    ver = SpeculativeVerifier(B, K, V, predictor=MinimalQualityPredictor())
+    ver.inv_temperature = 1.0 / 0.7
+    feat = torch.randn((B, 64), device="cuda", generator=g)
+    res = ver.step_hidden(hidden, lm.lm_head.weight, tok, lp_d, u, feat, logit_scale=lm.logit_scale)
+    two = ver.step(logits, tok, lp_d, u, feat)
+    torch.cuda.synchronize()
+    hb = hidden.reshape(B * K, -1).view(torch.int16).cpu().numpy().view(np.uint16)
+    wb = lm.lm_head.weight.detach().view(torch.int16).cpu().numpy().view(np.uint16)
+    inv_t = float(np.float32(np.float32(1.0 / 0.7) * np.float32(2.0)))
+    ref = O.lm_head_verify(hb, wb, tok.cpu().numpy(), lp_d.cpu().numpy(), u.cpu().numpy(), B, K, inv_t)
+    np.testing.assert_allclose(res.verify.lp_target.cpu().numpy(), ref["lp_t64"], rtol=0, atol=LMH_ATOL)
+    safe = ref["margin"] >= LMH_MARGIN
+    assert np.array_equal(res.verify.accept.cpu().numpy()[safe], ref["accept"][safe])
+    assert res.stop is not None and res.stop.score.shape == (B,)
+    assert (res.verify.lp_target - two.verify.lp_target).abs().max().item() < 0.1     # bf16 rounding of the logits
+
+
+def test_token_logprobs_from_hidden():
+    import torch
+
+    from asd_amd.training.logprobs import token_logprobs, token_logprobs_from_hidden
+
+    T, D, V = 70, 128, 900                   # T > 64: two launches
+    g = torch.Generator(device="cuda").manual_seed(5)
+    h = torch.randn((T, D), device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn((V, D), device="cuda", generator=g) * (2.0 / D ** 0.5)).to(torch.bfloat16)
+    tok = torch.randint(0, V, (T,), device="cuda", generator=g)
+    got = token_logprobs_from_hidden(h, w, tok).cpu().numpy()
+    exact = torch.log_softmax(h.double() @ w.double().T, -1).gather(1, tok[:, None])[:, 0].cpu().numpy()
+    np.testing.assert_allclose(got, exact, rtol=0, atol=LMH_ATOL)
+    scored = token_logprobs((h.float() @ w.float().T), tok)       # the reference-shaped call on materialised f32 scores
+    np.testing.assert_allclose(got, scored, rtol=0, atol=LMH_ATOL)
