@@ -96,6 +96,11 @@ def load_library() -> C.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension has not been built. "
                 "Run `python adaptive-speculative-decoding_amd/build.py` (needs hipcc). "
                 "There is no CPU fallback.")
+        # The library and PyTorch must share ONE HIP runtime: device pointers and streams come from torch.
+        # PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's); whichever is mapped first
+        # serves both, but only if torch's is first does torch use it too -- loaded the other way round the
+        # process holds two runtimes and every call here fails with a HIP error on torch's pointers.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             try:
