@@ -163,6 +163,141 @@ def load_traffic():
         return None, None
 
 
+LM_HEADS = {"7b": 3584, "14b": 5120, "32b": 5120, "72b": 8192}   # Qwen2.5 hidden sizes (configs/models.yaml)
+MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16
+
+
+def main_lm_head(args):
+    """`--lm-head SIZE`: the step starts one stage earlier -- from the target's final hidden
+    states [B, K, D] and its lm_head matrix [V, D]: asd_lm_head_verify (bf16 MFMA GEMM + log-sum-exp + accept,
+    logits never in HBM) + asd_predictor_stop.  Same contract as the default bench; roofline bound = mfma."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from asd_amd import kernels as Kmod
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if os.environ.get("ASD_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    red_dev = device if args.dist_backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.dist_backend, **({"device_id": device} if args.dist_backend == "nccl" else {}))
+
+    def barrier():
+        if world > 1:
+            dist.all_reduce(torch.zeros(1, device=red_dev))
+
+    B, K, V, desc = WORKLOADS[args.workload]
+    D = LM_HEADS[args.lm_head]
+    M = B * K
+    g = torch.Generator(device=device).manual_seed(4321 + rank)
+    w = (torch.randn((V, D), device=device, generator=g) * (3.0 / D ** 0.5)).to(torch.bfloat16)
+    nbuf = 4
+    bufs = []
+    for _ in range(nbuf):
+        h = torch.randn((M, D), device=device, generator=g).to(torch.bfloat16)
+        tok = torch.randint(0, V, (B, K), device=device, generator=g, dtype=torch.int32)
+        tok[:, ::2] = (h[::2].float() @ w.float().T).argmax(-1).reshape(B, -1)[:, : tok[:, ::2].shape[1]].to(torch.int32)
+        bufs.append(dict(h=h, tok=tok, lp_d=-torch.rand((B, K), device=device, generator=g) * 2,
+                         u=torch.rand((B, K), device=device, generator=g), out=None))
+    ver = Kmod.LmHeadVerifier(w, B, K)
+    packed = Kmod.pack_mlp_weights(*predictor_weights(np), device=device)
+    feat = torch.from_numpy((np.random.default_rng(7).standard_normal((B, 64)) * 0.3).astype(np.float32)).to(device)
+    Cc = torch.tensor(STAGE_COSTS, dtype=torch.float64, device=device)
+    p_hist = torch.ones((B, N_STAGES), dtype=torch.float64, device=device)
+
+    def step(i):
+        b = bufs[i % nbuf]
+        b["out"] = ver(b["h"], b["tok"], b["lp_d"], b["u"], out=b["out"])
+        if not args.verify_only:
+            Kmod.predictor_stop(feat, packed, 64, 32, stage_idx=0, L=N_STAGES, lp=b["out"].lp_target, stats_col=5,
+                                risk_adjustment=True, n_obs=100, p_hist=p_hist, Cc=Cc, lam=1.0)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tokens = sum(int(bufs[(args.warmup + i) % nbuf]["out"].n_acc.sum().item()) + B for i in range(args.steps))
+    # kernel-only: back-to-back fused calls (two GEMM launches + the merge launch) between two events
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    runs = []
+    for r in range(4):                                     # run 0 settles clocks / power state and is dropped
+        e0.record()
+        for i in range(30):
+            b = bufs[i % nbuf]
+            ver(b["h"], b["tok"], b["lp_d"], b["u"], out=b["out"])
+        e1.record()
+        torch.cuda.synchronize()
+        if r:
+            runs.append(e0.elapsed_time(e1) / 30)
+    kern_ms = sum(runs) / len(runs)
+    stats = torch.tensor([elapsed, float(tokens)], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats[1:].clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, tokens = float(tmax.item()), float(tsum.item())
+    if rank == 0:
+        flops = 2.0 * M * D * V
+        hbm = V * D * 2 + M * D * 2
+        out = {
+            "metric": "verified_tokens_per_s", "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload} from hidden states: {desc.split(';')[0]}; step = asd_lm_head_verify "
+                                   f"({args.lm_head} lm_head, D={D}: bf16 MFMA GEMM + log-sum-exp + accept, no logits in HBM)"
+                                   + ("" if args.verify_only else " + asd_predictor_stop"),
+                       "batch_per_gpu": B, "draft_len": K, "vocab": V, "hidden": D, "accumulate": "f32 MFMA (epilogue f64)",
+                       "rotating_buffers": nbuf, "launch_mode": "eager",
+                       "parallelism": f"batch-parallel replicas x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "asd::k_lm_head_tile<4> + <2> + k_accept_from_blocks (lm_head_verify.hip)",
+                         "algorithmic_flops": flops, "algorithmic_bytes": hbm,
+                         "hbm_GBs": hbm / (kern_ms * 1e-3) / 1e9, "hbm_frac": hbm / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_ms_mean": kern_ms, "kernel_ms_runs": runs,
+                         "timing": "HIP events around 3 runs of 30 back-to-back asd_lm_head_verify calls (after one settling run)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            vs = 8192                                           # bounded sample: the first 8192 vocabulary columns
+            b = bufs[0]
+            hb = b["h"].view(torch.int16).cpu().numpy().view(np.uint16)
+            wb = w[:vs].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+            tk = np.minimum(b["tok"].cpu().numpy(), vs - 1)
+            from threadpoolctl import threadpool_limits
+            cores = max(1, min(len(os.sched_getaffinity(0)), 16))   # the GPU box's CPU share for one GPU
+            t1 = time.perf_counter()
+            n = 0
+            with threadpool_limits(limits=cores):
+                while time.perf_counter() - t1 < min(args.cpu_budget_s, 10.0):
+                    O.lm_head_verify(hb, wb, tk, b["lp_d"].cpu().numpy(), b["u"].cpu().numpy(), B, K)
+                    n += 1
+            per_step = (time.perf_counter() - t1) / n * (V / vs)
+            out["cpu_baseline"] = {"value": M / per_step, "unit": "tokens/s (rows scored per second)",
+                                   "cores": cores, "kind": "port",
+                                   "sample": f"oracle.lm_head_verify (numpy f64 GEMM + f64 accept rule) on {vs} of {V} "
+                                             f"vocabulary columns, {n} passes, scaled by V/{vs}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +324,11 @@ def main():
                          "split over the ranks (B/rank = B/world)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + ASD_BENCH_ONE_DEVICE=1 rehearses the N>1 control flow with every rank on cuda:0")
+    ap.add_argument("--lm-head", choices=sorted(LM_HEADS), default=None,
+                    help="start the step from hidden states: asd_lm_head_verify with this Qwen2.5 lm_head size (N2)")
     args = ap.parse_args()
+    if args.lm_head:
+        return main_lm_head(args)
 
     import numpy as np
     import torch
