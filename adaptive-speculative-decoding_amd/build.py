@@ -27,6 +27,7 @@ SOURCES = {
     "api.hip": [],
     "verify_accept.hip": ["-ffp-contract=off"],   # hosts the in-kernel epilogue (predictor_device.hpp)
     "residual_sample.hip": [],
+    "commit.hip": [],
     "lm_head_verify.hip": ["-ffp-contract=off"],  # ends in the same finish_row arithmetic as verify_accept.hip
     "decision.hip": ["-ffp-contract=off"],
     "predictor.hip": ["-ffp-contract=off"],

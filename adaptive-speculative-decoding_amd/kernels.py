@@ -196,6 +196,21 @@ class LmHeadVerifier:
         return out
 
 
+def commit_step(tok: torch.Tensor, n_acc: torch.Tensor, drawn: torch.Tensor, seq_len: torch.Tensor,
+                out_tokens: torch.Tensor, n_commit: Optional[torch.Tensor] = None, max_len: Optional[int] = None) -> None:
+    """N3: append every sequence's accepted prefix + drawn token to its row of `out_tokens` and advance
+    `seq_len` in place (asd_commit_step).  tok [B,K] i32, n_acc / drawn / seq_len [B] i32, out_tokens [B, T] i32."""
+    Bv, K = tok.shape
+    if out_tokens.dim() != 2 or out_tokens.shape[0] != Bv or out_tokens.stride(1) != 1:
+        raise ValueError("out_tokens must be [B, T] int32 with contiguous rows")
+    cap = out_tokens.shape[1] if max_len is None else int(max_len)
+    rc = _lib().asd_commit_step(_dev(tok, "tok", torch.int32), _dev(n_acc, "n_acc", torch.int32),
+                                _dev(drawn, "drawn", torch.int32), Bv, K, _dev(seq_len, "seq_len", torch.int32),
+                                _dev(out_tokens, "out_tokens", torch.int32), out_tokens.stride(0),
+                                _opt(n_commit, "n_commit", torch.int32), cap, _stream())
+    B.check("asd_commit_step", rc)
+
+
 # ------------------------------------------------------------------------------- predictor side
 def logprob_stats(lp: torch.Tensor, n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """A7: [B,K] f32 log-probs -> [B,5] f64 (mean, std, min, q25, median), numpy semantics."""

@@ -200,3 +200,89 @@ def speculative_generate(draft, target, prompt_ids: torch.Tensor, max_new_tokens
         d_logits = draft(seq[:, draft.cached_len:])[:, -1]
         t_last = target(seq[:, target.cached_len:])[:, -1]
     return GenerationTrace(torch.cat(out_tokens, 1)[:, :max_new_tokens], steps, verified, masks, inputs, stops)
+
+
+@dataclass
+class RaggedTrace:
+    tokens: torch.Tensor            # [B, P + max_new_tokens] int32: prompt + committed tokens, row b valid up to seq_len[b]
+    seq_len: torch.Tensor           # [B] int32
+    steps: int
+    verified_tokens: int            # sum over steps and sequences of the tokens actually appended
+    accept_masks: List[torch.Tensor]
+    step_inputs: List[dict]
+    commits: List[torch.Tensor]     # per step: n_commit [B]
+
+
+@torch.no_grad()
+def speculative_generate_ragged(draft, target, prompt_ids: torch.Tensor, max_new_tokens: int,
+                                verifier: SpeculativeVerifier, *, temperature: float = 1.0, seed: int = 0,
+                                feat: Optional[torch.Tensor] = None, keep_inputs: bool = False,
+                                sync_every: int = 4) -> RaggedTrace:
+    """The loop with per-sequence lengths: every sequence commits ITS n_acc + 1 tokens per
+    step (no lock-step minimum), both KV caches are per-sequence and rolling back after a rejection is the
+    length update asd_commit_step does on the device.  The host reads nothing back inside a step; it looks
+    at min(seq_len) every `sync_every` steps to decide whether to stop.
+
+    Invariant at the top of a step, L = seq_len[b]: tokens[b, :L] are committed; the target's KV is valid
+    for positions < L - 1 and the draft's for positions < L - 2 (at least), so the target is fed
+    [t_{L-1}, d_0 .. d_{K-1}] at position L - 1 (row i scores d_i, row K is the bonus row) and the draft first
+    re-feeds the last two committed tokens."""
+    dev = prompt_ids.device
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    B, P = prompt_ids.shape
+    Kd = verifier.Kd
+    if P < 2:
+        raise ValueError("the ragged loop needs a prompt of at least two tokens")
+    verifier.inv_temperature = 1.0 / temperature
+    cap = P + max_new_tokens
+    for m in (draft, target):
+        m.reset()
+        m.alloc_ragged(B, cap + Kd + 2)
+    tokens = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    tokens[:, :P] = prompt_ids.to(torch.int32)
+    seq_len = torch.full((B,), P, dtype=torch.int32, device=dev)
+    n_commit = torch.zeros((B,), dtype=torch.int32, device=dev)
+    zero = torch.zeros((B,), dtype=torch.int64, device=dev)
+    target.forward_ragged(prompt_ids[:, :P - 1], zero, P)            # prefill: everything but the last prompt token
+    if P > 2:
+        draft.forward_ragged(prompt_ids[:, :P - 2], zero, P)
+    rows = torch.arange(B, device=dev)
+    masks, inputs, commits = [], [], []
+    verified = torch.zeros((), dtype=torch.int64, device=dev)
+    steps = 0
+    while True:
+        L = seq_len.to(torch.int64)
+        window = min(P + steps * (Kd + 1) + Kd + 1, cap + Kd + 2)    # host-side bound on every position touched this step
+        last2 = torch.stack([tokens[rows, L - 2], tokens[rows, L - 1]], 1).to(torch.int64)
+        dl = draft.forward_ragged(last2, L - 2, window)[:, -1]
+        toks, lps, dls = [], [], []
+        for k in range(Kd):
+            t, lp = _sample(dl, temperature, gen)
+            toks.append(t)
+            lps.append(lp)
+            dls.append(dl)
+            if k + 1 < Kd:
+                dl = draft.forward_ragged(t[:, None], L + k, window)[:, -1]
+        tok = torch.stack(toks, 1)
+        lp_d = torch.stack(lps, 1).contiguous()
+        t_out = target.forward_ragged(torch.cat([last2[:, 1:], tok], 1), L - 1, window)     # [B, K+1, V]
+        score = t_out[:, :Kd].contiguous()
+        u = torch.rand((B, Kd), generator=gen, device=dev)
+        tok32 = tok.to(torch.int32).contiguous()
+        res = verifier.step(score, tok32, lp_d, u, feat)
+        r = torch.rand((B,), generator=gen, device=dev)
+        drawn = verifier.sampler(score, torch.stack(dls, 1).to(score.dtype).contiguous(), res.verify.n_acc, r,
+                                 bonus_logits=t_out[:, Kd].contiguous(), inv_temperature=verifier.inv_temperature)
+        K.commit_step(tok32, res.verify.n_acc, drawn, seq_len, tokens, n_commit, max_len=cap)
+        verified += n_commit.sum()
+        masks.append(res.verify.accept.clone())
+        commits.append(n_commit.clone())
+        if keep_inputs:
+            inputs.append(dict(logits=score.clone(), tok=tok32.clone(), lp_d=lp_d.clone(), u=u.clone(),
+                               n_acc=res.verify.n_acc.clone(), drawn=drawn.clone()))
+        steps += 1
+        if steps % sync_every == 0 and int(seq_len.min().item()) >= cap:
+            break
+        if steps > max_new_tokens + sync_every:      # cannot happen: every step appends >= 1 token per unfinished row
+            raise RuntimeError("ragged loop did not terminate")
+    return RaggedTrace(tokens, seq_len, steps, int(verified.item()), masks, inputs, commits)

@@ -68,11 +68,11 @@ class RMSNorm(nn.Module):
 
 
 def _rope(x: torch.Tensor, pos: torch.Tensor, theta: float) -> torch.Tensor:
-    """x: [B, H, T, D]; pos: [T] absolute positions."""
+    """x: [B, H, T, D]; pos: [T] absolute positions shared by the batch, or [B, T] per sequence."""
     d = x.shape[-1]
     inv = 1.0 / (theta ** (torch.arange(0, d, 2, device=x.device, dtype=torch.float32) / d))
-    ang = pos.float()[:, None] * inv[None, :]
-    cos, sin = ang.cos()[None, None], ang.sin()[None, None]
+    ang = pos.float()[..., None] * inv
+    cos, sin = (ang.cos()[None, None], ang.sin()[None, None]) if pos.dim() == 1 else (ang.cos()[:, None], ang.sin()[:, None])
     x1, x2 = x.float()[..., : d // 2], x.float()[..., d // 2:]
     return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1).to(x.dtype)
 
@@ -115,8 +115,35 @@ class Block(nn.Module):
         return x + self.down(F.silu(self.gate(h)) * self.up(h)), new_cache
 
 
+    def forward_ragged(self, x, pos, kbuf, vbuf, window: int):
+        """Per-sequence positions (N3): x [B, T, D], pos [B, T] int64; kbuf / vbuf [B, Hkv, Tmax, hd] are
+        written in place at `pos`, and query (b, t) attends keys j <= pos[b, t] of the first `window` slots.
+        Entries past a sequence's committed length are never read before they are rewritten, so rolling a
+        sequence back is a length update on the caller's side."""
+        s = self.s
+        B, T, _ = x.shape
+        h = self.ln1(x)
+        q = self.q(h).view(B, T, s.heads, s.head_dim).transpose(1, 2)
+        k = self.k(h).view(B, T, s.kv_heads, s.head_dim).transpose(1, 2)
+        v = self.v(h).view(B, T, s.kv_heads, s.head_dim).transpose(1, 2)
+        q, k = _rope(q, pos, s.rope_theta), _rope(k, pos, s.rope_theta)
+        bidx = torch.arange(B, device=x.device)[:, None].expand(B, T)
+        kbuf[bidx, :, pos] = k.transpose(1, 2)
+        vbuf[bidx, :, pos] = v.transpose(1, 2)
+        kk, vv = kbuf[:, :, :window], vbuf[:, :, :window]
+        rep = s.heads // s.kv_heads
+        if rep > 1:
+            kk, vv = kk.repeat_interleave(rep, dim=1), vv.repeat_interleave(rep, dim=1)
+        mask = (torch.arange(window, device=x.device)[None, None, :] <= pos[:, :, None])[:, None]   # [B, 1, T, window]
+        a = F.scaled_dot_product_attention(q, kk, vv, attn_mask=mask)
+        x = x + self.o(a.transpose(1, 2).reshape(B, T, s.hidden))
+        h = self.ln2(x)
+        return x + self.down(F.silu(self.gate(h)) * self.up(h))
+
+
 class SyntheticLM(nn.Module):
-    """Decoder-only LM with a KV cache that can be rolled back (`truncate`) after a rejection."""
+    """Decoder-only LM with a KV cache that can be rolled back after a rejection: `truncate` for the
+    lock-step cache (one length for the batch), `alloc_ragged` / `forward_ragged` for per-sequence lengths."""
 
     def __init__(self, shape: LMShape, dtype: torch.dtype = torch.bfloat16, device=None, seed: int = 0,
                  logit_scale: float = 1.0):
@@ -144,11 +171,36 @@ class SyntheticLM(nn.Module):
         self.eval()
         self._cache: List[Optional[Tuple[torch.Tensor, torch.Tensor]]] = [None] * shape.layers
         self._len = 0
+        self._ragged = None
 
     # -- cache management
     def reset(self):
         self._cache = [None] * self.shape.layers
         self._len = 0
+        self._ragged = None
+
+    def alloc_ragged(self, batch: int, max_len: int):
+        """Per-sequence KV cache (N3): one [B, Hkv, max_len, hd] K and V buffer per layer, zero-filled."""
+        p = next(self.parameters())
+        shape = (batch, self.shape.kv_heads, max_len, self.shape.head_dim)
+        self._ragged = [(torch.zeros(shape, dtype=p.dtype, device=p.device), torch.zeros(shape, dtype=p.dtype, device=p.device))
+                        for _ in range(self.shape.layers)]
+
+    @torch.no_grad()
+    def forward_ragged(self, ids: torch.Tensor, pos0: torch.Tensor, window: int, return_hidden: bool = False):
+        """ids [B, T] placed at positions pos0[b] .. pos0[b]+T-1 of sequence b (pos0: [B] integer tensor);
+        `window` is a host-side upper bound on any position in use (no device read-back).  KV entries at
+        those positions are (re)written; nothing else changes.  Returns logits [B, T, V] (or hidden states)."""
+        assert self._ragged is not None, "call alloc_ragged first"
+        B, T = ids.shape
+        pos = pos0.to(torch.int64)[:, None] + torch.arange(T, device=ids.device)
+        x = self.embed(ids)
+        for blk, (kb, vb) in zip(self.blocks, self._ragged):
+            x = blk.forward_ragged(x, pos, kb, vb, window)
+        x = self.norm(x)
+        if return_hidden:
+            return x
+        return self.lm_head(x) * self.logit_scale
 
     @property
     def cached_len(self) -> int:

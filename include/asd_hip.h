@@ -145,6 +145,18 @@ int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* weight, int
                        uint64_t* accept_bits, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * N3  commit / KV rollback bookkeeping of one token-level step, on the device.
+ * The reference's src/serving/cache_manager.py:149-190 `truncate_at_stage` trims a dict of strings;
+ * with a per-sequence KV cache the rollback after a rejection is a length update.  Row b of the token
+ * buffer `out_tokens` ([B][ld_out] i32) receives tok[b, 0..n_acc[b]) followed by drawn[b] (the residual /
+ * bonus token of asd_residual_sample) at index seq_len[b]; seq_len[b] += n_acc[b] + 1, clamped to
+ * max_len (tokens past max_len are dropped); n_commit[b] (may be NULL) = tokens appended.  n_acc is
+ * clamped to [0, K].  No host synchronisation is needed to learn n_acc. */
+int asd_commit_step(const int32_t* tok /*[B,K]*/, const int32_t* n_acc /*[B]*/, const int32_t* drawn /*[B]*/,
+                    int B, int K, int32_t* seq_len /*[B] in/out*/, int32_t* out_tokens /*[B][ld_out]*/,
+                    int64_t ld_out, int32_t* n_commit /*[B] out, may be NULL*/, int32_t max_len, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A7  log-prob statistics: features [5..9] of extract_features,
  * src/training/generate_training_data.py:166-175 -- np.mean, np.std (population), np.min,
  * np.percentile(.,25) (linear interpolation), np.median, all in float64 like numpy.

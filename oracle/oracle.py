@@ -196,6 +196,25 @@ def lm_head_verify(hidden_bits: np.ndarray, weight_bits: np.ndarray, tok, lp_d, 
     return dict(lp_t64=lp, accept=acc, n_acc=n_acc, bits=bits, margin=margin, logits64=x.reshape(B, K, V))
 
 
+def commit_step(tok, n_acc, drawn, seq_len, out_tokens, max_len: Optional[int] = None):
+    """N3 oracle (numpy, integer): returns (new seq_len, new out_tokens, n_commit); inputs are not modified."""
+    tok = np.asarray(tok, dtype=np.int32)
+    B, K = tok.shape
+    out = np.array(out_tokens, dtype=np.int32, copy=True)
+    lens = np.array(seq_len, dtype=np.int32, copy=True)
+    cap = out.shape[1] if max_len is None else int(max_len)
+    n_commit = np.zeros(B, np.int32)
+    for b in range(B):
+        na = int(min(max(int(n_acc[b]), 0), K))
+        new = list(tok[b, :na]) + [int(drawn[b])]
+        room = max(0, cap - int(lens[b]))
+        new = new[:room]
+        out[b, lens[b]:lens[b] + len(new)] = new
+        n_commit[b] = len(new)
+        lens[b] += len(new)
+    return lens, out, n_commit
+
+
 # ----------------------------------------------------------------------------- A7
 def logprob_stats(lp, n_valid=None, K: Optional[int] = None) -> np.ndarray:
     lib = _load()

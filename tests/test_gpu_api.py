@@ -166,3 +166,63 @@ def test_vocab_sharded_verifier_single_rank_nccl():
         assert np.array_equal(bv.gather_n_acc(out[2]).cpu().numpy(), case["ref"]["n_acc"])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,K", [(1, 1), (5, 8), (3, 64)])
+def test_commit_step_matches_oracle(B, K):
+    """N3: asd_commit_step (token buffer append + length update) is integer work: bit-exact vs the oracle,
+    including the clamp at max_len and out-of-range n_acc."""
+    import torch
+    from asd_amd import kernels as Kn
+    rng = np.random.default_rng(B * 100 + K)
+    T = 40
+    tok = rng.integers(0, 1000, (B, K)).astype(np.int32)
+    n_acc = rng.integers(-1, K + 2, B).astype(np.int32)          # -1 and K+1 are clamped
+    drawn = rng.integers(0, 1000, B).astype(np.int32)
+    seq_len = rng.integers(2, T + 1, B).astype(np.int32)           # some rows are full already
+    out = rng.integers(0, 1000, (B, T)).astype(np.int32)
+    lens_ref, out_ref, nc_ref = O.commit_step(tok, n_acc, drawn, seq_len, out, max_len=T)
+    d = lambda a: torch.from_numpy(a.copy()).cuda()  # noqa: E731
+    seq_d, out_d, nc_d = d(seq_len), d(out), torch.zeros(B, dtype=torch.int32, device="cuda")
+    Kn.commit_step(d(tok), d(n_acc), d(drawn), seq_d, out_d, nc_d, max_len=T)
+    torch.cuda.synchronize()
+    assert np.array_equal(seq_d.cpu().numpy(), lens_ref)
+    assert np.array_equal(out_d.cpu().numpy(), out_ref)
+    assert np.array_equal(nc_d.cpu().numpy(), nc_ref)
+
+
+def test_ragged_loop_commits_per_sequence_and_matches_oracle():
+    """N3: the per-sequence loop.  Accept masks vs the oracle on the recorded inputs; the token buffer is
+    exactly prompt + per-step (accepted prefix + drawn token); different sequences advance at different rates."""
+    import torch
+    from asd_amd.serving import synthetic_lm as SL
+    from asd_amd.serving.speculative import SpeculativeVerifier, speculative_generate_ragged
+    B, K, V, P, NEW = 4, 4, 1000, 6, 24
+    torch.manual_seed(0)
+    target = SL.SyntheticLM(SL.tiny(vocab=V, hidden=128, layers=2), device="cuda", seed=1, logit_scale=6.0)
+    draft = SL.SyntheticLM(SL.tiny(vocab=V, hidden=128, layers=2), device="cuda", seed=1, logit_scale=5.0)   # a close draft
+    prompt = torch.randint(0, V, (B, P), device="cuda")
+    ver = SpeculativeVerifier(B, K, V)
+    tr = speculative_generate_ragged(draft, target, prompt, NEW, ver, temperature=1.0, seed=3, keep_inputs=True, sync_every=2)
+    lens = tr.seq_len.cpu().numpy()
+    assert (lens == P + NEW).all()
+    toks = tr.tokens.cpu().numpy()
+    assert np.array_equal(toks[:, :P], prompt.cpu().numpy())
+    cur = np.full(B, P)
+    total = 0
+    for step, inp in enumerate(tr.step_inputs):
+        lg = inp["logits"].view(torch.int16).cpu().numpy().view(np.uint16).reshape(B * K, V)
+        ref = O.verify_accept(lg, O.DT_BF16, inp["tok"].cpu().numpy(), inp["lp_d"].cpu().numpy(), inp["u"].cpu().numpy(), B, K, V)
+        safe = ref["margin"] >= 1e-4
+        assert np.array_equal(tr.accept_masks[step].cpu().numpy()[safe], ref["accept"][safe])
+        n_acc, drawn, tk = inp["n_acc"].cpu().numpy(), inp["drawn"].cpu().numpy(), inp["tok"].cpu().numpy()
+        nc = tr.commits[step].cpu().numpy()
+        for b in range(B):
+            new = (list(tk[b, :n_acc[b]]) + [drawn[b]])[: max(0, P + NEW - cur[b])]
+            assert nc[b] == len(new)
+            assert list(toks[b, cur[b]:cur[b] + len(new)]) == new
+            cur[b] += len(new)
+        total += int(nc.sum())
+    assert total == tr.verified_tokens == B * NEW
+    per_seq_steps = [sum(1 for c in tr.commits if c[b].item() > 0) for b in range(B)]
+    assert tr.steps < NEW and len(set(per_seq_steps)) >= 1

@@ -385,3 +385,31 @@ def test_config_surface_yaml(tmp_path):
         assert 0 <= dec2.decode("why?").selected_stage < 4
     finally:
         os.chdir(cwd)
+
+
+def test_ragged_kv_forward_equals_full_context_and_survives_rollback():
+    """N3 plumbing (CPU, fp32): per-sequence positions reproduce the dense forward; after a 'rollback'
+    (a shorter length on the caller's side) stale KV entries are overwritten before they are read."""
+    import torch
+
+    from asd_amd.serving import synthetic_lm as SL
+
+    lm = SL.SyntheticLM(SL.tiny(vocab=60, hidden=32, layers=2, heads=4, kv_heads=2), dtype=torch.float32, device="cpu", seed=1)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 60, (3, 9), generator=g)
+    full = lm(ids)
+    lm.reset()
+    lm.alloc_ragged(3, 16)
+    zero = torch.zeros(3, dtype=torch.int64)
+    a = lm.forward_ragged(ids[:, :5], zero, 12)
+    # garbage continuation at per-sequence positions (a rejected draft), then the real tokens over it
+    lm.forward_ragged(torch.randint(0, 60, (3, 3), generator=g), torch.tensor([5, 4, 3]), 12)
+    # sequence b resumes from its own length (5, 4, 3) with the true tokens
+    pos0 = torch.tensor([5, 4, 3])
+    T = 4
+    chunk = torch.stack([ids[b, pos0[b]:pos0[b] + T] for b in range(3)])
+    out = lm.forward_ragged(chunk, pos0, 12)
+    for b in range(3):
+        lo = int(pos0[b])
+        torch.testing.assert_close(out[b], full[b, lo:lo + T], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a, full[:, :5], rtol=1e-4, atol=1e-5)

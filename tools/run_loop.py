@@ -23,7 +23,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from asd_amd.minimal_adaptive_decoder import MinimalQualityPredictor  # noqa: E402
-from asd_amd.serving.speculative import SpeculativeVerifier, speculative_generate  # noqa: E402
+from asd_amd.serving.speculative import (SpeculativeVerifier, speculative_generate,  # noqa: E402
+                                             speculative_generate_ragged)
 from asd_amd.serving.synthetic_lm import QWEN25_SHAPES, SyntheticLM, tiny  # noqa: E402
 
 
@@ -38,6 +39,8 @@ def main():
     ap.add_argument("--logit-scale", type=float, default=0.6,
                     help="random-weight logits are scaled so that two unrelated models still accept some tokens")
     ap.add_argument("--check-steps", type=int, default=2)
+    ap.add_argument("--ragged", action="store_true",
+                    help="per-sequence commit (N3: ragged KV + asd_commit_step) instead of the lock-step minimum")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "loop.json"))
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -53,10 +56,11 @@ def main():
     ver = SpeculativeVerifier(a.batch, a.draft_len, V, predictor=pred, lambda_value=1.0, stage_costs=(1.0, 4.5, 10.0))
     prompt = torch.randint(0, V, (a.batch, a.prompt_len), device=dev)
     feat = torch.zeros((a.batch, 64), device=dev)
-    speculative_generate(draft, target, prompt, a.draft_len + 1, ver, seed=3, feat=feat)      # warm-up (GEMM autotune)
+    loop = speculative_generate_ragged if a.ragged else speculative_generate
+    loop(draft, target, prompt, a.draft_len + 1, ver, seed=3, feat=feat)      # warm-up (GEMM autotune)
     torch.cuda.synchronize()
     t0 = time.time()
-    tr = speculative_generate(draft, target, prompt, a.new_tokens, ver, seed=4, feat=feat, keep_inputs=True)
+    tr = loop(draft, target, prompt, a.new_tokens, ver, seed=4, feat=feat, keep_inputs=True)
     torch.cuda.synchronize()
     loop_s = time.time() - t0
 
@@ -80,14 +84,19 @@ def main():
         mism += int((mask.cpu().numpy()[ok] != ref["accept"][ok]).sum())
         checked += int(ok.sum())
     acc_rate = float(np.mean([m.float().mean().item() for m in tr.accept_masks]))
+    committed = int(tr.seq_len.sum().item()) - a.batch * a.prompt_len if a.ragged else tr.tokens.numel()
     out = dict(draft=shapes[a.draft].name, target=shapes[a.target].name, batch=a.batch, draft_len=a.draft_len, vocab=V,
                params_B=[round(shapes[a.draft].param_count() / 1e9, 2), round(shapes[a.target].param_count() / 1e9, 2)],
                hbm_GB_allocated=round(torch.cuda.max_memory_allocated() / 1e9, 1), build_s=round(build_s, 1),
                steps=tr.steps, verified_tokens=tr.verified_tokens, loop_s=loop_s,
-               verified_tokens_per_s=tr.verified_tokens / loop_s, ms_per_step=1e3 * loop_s / tr.steps,
+               verified_tokens_per_s=tr.verified_tokens / loop_s, committed_tokens=committed,
+               committed_tokens_per_s=committed / loop_s, ms_per_step=1e3 * loop_s / tr.steps,
                hot_path_ms_per_step=hot_ms / tr.steps, hot_path_share=hot_ms / 1e3 / loop_s,
                mean_accept_rate=acc_rate, mask_positions_checked=checked, mask_mismatches=mism,
-               stop_rate=float(np.mean([s.float().mean().item() for s in tr.stop_flags if s is not None])))
+               commit="per-sequence (ragged KV, asd_commit_step)" if a.ragged else "lock-step min_b(n_acc)+1",
+               tokens_per_step_per_seq=tr.verified_tokens / tr.steps / a.batch)
+    if not a.ragged:
+        out["stop_rate"] = float(np.mean([s.float().mean().item() for s in tr.stop_flags if s is not None]))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)
