@@ -43,6 +43,8 @@ SIGNATURES = {
     "asd_lm_head_verify_workspace_bytes": (_sz, [_i, _i, _i]),
     "asd_lm_head_verify": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                 _sz, _vp]),
+    "asd_lm_head_verify_ex": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _sz, _vp]),
     "asd_commit_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),
     "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
     "asd_mlp_packed_floats": (_sz, [_i, _i]),

@@ -45,6 +45,8 @@ typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int kBM = 256;        // rows (draft positions) per workgroup: 4 wave rows x 64
 constexpr int kSuper = 64;      // reduction columns per superstage = one 128-byte line per row
 constexpr int kThreads = 512;
+constexpr int kMsg = 5;         // floats per (block, row) record: m2, s, g, arg-max value, arg-max id (int bits)
+constexpr int kNoIndex = 0x7fffffff;
 constexpr int kWRing = 3;       // LDS slots of one weight superstage each (two in flight, one multiplied)
 constexpr int kHRing = 2;       // LDS slots of one hidden superstage each
 
@@ -56,7 +58,7 @@ struct LmHeadParams {
     int D, M, V;
     const int32_t* tok;
     float c2;
-    float* msg;          // [blocks of both launches][M][3]
+    float* msg;          // [blocks of both launches][M][kMsg]
     int m_blocks;
     int col0;            // first vocabulary column of this launch
     int unit0;           // index of this launch's first block in msg (one triple per row and block)
@@ -202,15 +204,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     // ---- epilogue: D[vocab row][m column]; lane (r, h) holds row m and, per 32-column tile, the 16
     // vocabulary ids  n = tile + (i & 3) + 8 * (i >> 2) + 4 * h.  A wave folds its 32 * NTW columns per row,
     // the two wave columns meet in LDS (free now: every DMA was retired by the last wait), and the block
-    // writes ONE (m2, s, g) triple per row.
-    float* const meet = reinterpret_cast<float*>(lds);   // [256 rows][3]
+    // writes ONE record per row: (m2, s, g) and the block's arg-max (value, vocabulary id; ties -> lowest id,
+    // NaN logits never win).
+    float* const meet = reinterpret_cast<float*>(lds);   // [256 rows][kMsg]
     __syncthreads();                                      // the last superstage's fragment reads are done
-    float tm2[2], ts[2], tg[2];
+    float tm2[2], ts[2], tg[2], tbv[2];
+    int tbi[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + 64 * wm + 32 * mt + r;
         const int tk = (wave_works && m < p.M) ? p.tok[m] : -1;
-        float m2 = kSentinel, s = 0.0f, g = -INFINITY;
+        float m2 = kSentinel, s = 0.0f, g = -INFINITY, bv = -INFINITY;
+        int bi = kNoIndex;
         if (wave_works) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
                     const int n = n0 + 32 * NTW * wn + 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * h;
                     const float v = n < p.V ? acc[mt][nt][i] : -INFINITY;   // padded weight rows are not vocabulary
                     if (n == tk) g = v;
+                    if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
                     x[i] = v;
                 }
                 float lo[8], hi[8];
@@ -233,12 +239,15 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         const float m2o = __shfl_xor(m2, 32, 64);
         const float so = __shfl_xor(s, 32, 64);
         const float go = __shfl_xor(g, 32, 64);
+        const float bvo = __shfl_xor(bv, 32, 64);
+        const int bio = __shfl_xor(bi, 32, 64);
         ms_merge(m2, s, m2o, so);
         g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));   // a NaN logit must not be dropped by max
-        tm2[mt] = m2; ts[mt] = s; tg[mt] = g;
+        if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+        tm2[mt] = m2; ts[mt] = s; tg[mt] = g; tbv[mt] = bv; tbi[mt] = bi;
         if (wn == 1 && h == 0) {
-            float* q = meet + (64 * wm + 32 * mt + r) * 3;
-            q[0] = m2; q[1] = s; q[2] = g;
+            float* q = meet + (64 * wm + 32 * mt + r) * kMsg;
+            q[0] = m2; q[1] = s; q[2] = g; q[3] = bv; q[4] = __int_as_float(bi);
         }
     }
     __syncthreads();
@@ -247,24 +256,34 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + 64 * wm + 32 * mt + r;
         if (m >= p.M) continue;
-        const float* q = meet + (64 * wm + 32 * mt + r) * 3;
-        float m2 = tm2[mt], s = ts[mt], g = tg[mt];
+        const float* q = meet + (64 * wm + 32 * mt + r) * kMsg;
+        float m2 = tm2[mt], s = ts[mt], g = tg[mt], bv = tbv[mt];
+        int bi = tbi[mt];
         ms_merge(m2, s, q[0], q[1]);
         const float go = q[2];
         g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));
-        float* out = p.msg + (static_cast<int64_t>(p.unit0 + nb) * p.M + m) * 3;
+        const float bvo = q[3];
+        const int bio = __float_as_int(q[4]);
+        if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+        float* out = p.msg + (static_cast<int64_t>(p.unit0 + nb) * p.M + m) * kMsg;
         out[0] = m2;
         out[1] = s;
         out[2] = g;
+        out[3] = bv;
+        out[4] = __int_as_float(bi);
     }
 }
 
-// merge the per-block triples of every row of sequence b, then the accept rule.  Up to 16 waves; wave w
+// merge the per-block records of every row of sequence b, then the accept rule.  Up to 16 waves; wave w
 // takes draft positions w, w + waves, ...; its lanes stride over the blocks (fixed order: deterministic).
+// greedy != 0: accept[b,k] = (tok[b,k] == argmax_v logits[b,k,v]) instead of the sampling test
+// (lp_d / u unused); argmax_out (may be NULL) receives the row arg-max either way (-1: no finite logit).
 __global__ __launch_bounds__(1024) void k_accept_from_blocks(const float* msg, int n_blocks, const float* lp_d,
-                                                            const float* u, int B, int K, float c2, float* lp_t,
-                                                            uint8_t* accept, int32_t* n_acc, uint64_t* bits) {
+                                                            const float* u, const int32_t* tok, int greedy, int B, int K,
+                                                            float c2, float* lp_t, uint8_t* accept, int32_t* n_acc,
+                                                            uint64_t* bits, int32_t* argmax_out) {
     __shared__ float red[ASD_MAX_DRAFT_LEN][3];
+    __shared__ int best[ASD_MAX_DRAFT_LEN];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -272,22 +291,31 @@ __global__ __launch_bounds__(1024) void k_accept_from_blocks(const float* msg, i
     const int64_t M = static_cast<int64_t>(B) * K;
     for (int k = w; k < K; k += waves) {
         const int64_t row = static_cast<int64_t>(b) * K + k;
-        float m2 = kSentinel, s = 0.0f, g = -INFINITY;
+        float m2 = kSentinel, s = 0.0f, g = -INFINITY, bv = -INFINITY;
+        int bi = kNoIndex;
         bool gnan = false;
         for (int j = lane; j < n_blocks; j += 64) {
-            const float* t = msg + (static_cast<int64_t>(j) * M + row) * 3;
+            const float* t = msg + (static_cast<int64_t>(j) * M + row) * kMsg;
             ms_merge(m2, s, t[0], t[1]);
             const float gj = t[2];
             gnan = gnan || (gj != gj);
             g = fmaxf(g, gj);
+            const float bvj = t[3];
+            const int bij = __float_as_int(t[4]);
+            if (bvj > bv || (bvj == bv && bij < bi)) { bv = bvj; bi = bij; }
         }
         wave_merge(m2, s);
         g = wave_max(g);
         if (__ballot(gnan) != 0ull) g = NAN;
+        const float top = wave_max(bv);
+        int cand = (bv == top) ? bi : kNoIndex;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
         if (lane == 0) {
             red[k][0] = m2;
             red[k][1] = s;
             red[k][2] = g;
+            best[k] = cand == kNoIndex ? -1 : cand;
         }
     }
     __syncthreads();
@@ -296,9 +324,13 @@ __global__ __launch_bounds__(1024) void k_accept_from_blocks(const float* msg, i
     if (lane < K) {
         const int64_t row = static_cast<int64_t>(b) * K + lane;
         float lp;
-        flag = finish_row(red[lane][0], red[lane][1], red[lane][2], c2, lp_d[row], log_u(u[row]), lp);
+        const float lpd = greedy ? 0.0f : lp_d[row];
+        const double lu = greedy ? 0.0 : log_u(u[row]);
+        flag = finish_row(red[lane][0], red[lane][1], red[lane][2], c2, lpd, lu, lp);
+        if (greedy) flag = best[lane] >= 0 && tok[row] == best[lane];
         lp_t[row] = lp;
         accept[row] = flag ? 1 : 0;
+        if (argmax_out) argmax_out[row] = best[lane];
     }
     finish_sequence(flag, lane, K, b, n_acc, bits);
 }
@@ -313,19 +345,21 @@ using namespace asd;
 
 ASD_EXPORT size_t asd_lm_head_verify_workspace_bytes(int B, int K, int V) {
     if (B <= 0 || K <= 0 || V <= 0) return 0;
-    return round_up(static_cast<size_t>(max_blocks_for(V)) * static_cast<size_t>(B) * K * 3 * sizeof(float), 256);
+    return round_up(static_cast<size_t>(max_blocks_for(V)) * static_cast<size_t>(B) * K * kMsg * sizeof(float), 256);
 }
 
-ASD_EXPORT int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* weight, int64_t ld_w, int dtype, int D,
-                                  const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
-                                  float inv_temperature, float* lp_target, uint8_t* accept, int32_t* n_acc,
-                                  uint64_t* accept_bits, void* workspace, size_t workspace_bytes, void* stream) {
+ASD_EXPORT int asd_lm_head_verify_ex(const void* hidden, int64_t ld_h, const void* weight, int64_t ld_w, int dtype, int D,
+                                     const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
+                                     float inv_temperature, int greedy, float* lp_target, uint8_t* accept,
+                                     int32_t* n_acc, uint64_t* accept_bits, int32_t* argmax_out, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
     if (B < 0 || K < 0 || V < 1 || D < 1) return ASD_ERR_INVALID_ARG;
     if (!(inv_temperature > 0.0f) || !(inv_temperature < 3.0e38f)) return ASD_ERR_INVALID_ARG;
     if (B == 0 || K == 0) return ASD_OK;
     if (K > ASD_MAX_DRAFT_LEN) return ASD_ERR_UNSUPPORTED;
     if (dtype != ASD_DTYPE_BF16 || D % kSuper != 0) return ASD_ERR_UNSUPPORTED;
-    if (!hidden || !weight || !tok || !lp_draft || !u || !lp_target || !accept || !n_acc) return ASD_ERR_INVALID_ARG;
+    if (!hidden || !weight || !tok || !lp_target || !accept || !n_acc) return ASD_ERR_INVALID_ARG;
+    if (!greedy && (!lp_draft || !u)) return ASD_ERR_INVALID_ARG;
     if (ld_h < D || ld_w < D) return ASD_ERR_INVALID_ARG;
     if (!aligned_to(hidden, 16) || !aligned_to(weight, 16) || ld_h % 8 != 0 || ld_w % 8 != 0) return ASD_ERR_ALIGNMENT;
     if (!workspace || workspace_bytes < asd_lm_head_verify_workspace_bytes(B, K, V)) return ASD_ERR_WORKSPACE;
@@ -356,7 +390,16 @@ ASD_EXPORT int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* 
         p.unit0 = static_cast<int>(wide);
         hipLaunchKernelGGL(k_lm_head_tile<2>, dim3(static_cast<unsigned>(narrow * m_blocks)), dim3(kThreads), 0, st, p);
     }
-    hipLaunchKernelGGL(k_accept_from_blocks, dim3(B), dim3(64 * (K < 16 ? K : 16)), 0, st, p.msg, static_cast<int>(wide + narrow), lp_draft, u, B, K, p.c2,
-                       lp_target, accept, n_acc, accept_bits);
+    hipLaunchKernelGGL(k_accept_from_blocks, dim3(B), dim3(64 * (K < 16 ? K : 16)), 0, st, p.msg,
+                       static_cast<int>(wide + narrow), lp_draft, u, tok, greedy ? 1 : 0, B, K, p.c2, lp_target, accept,
+                       n_acc, accept_bits, argmax_out);
     return launch_status();
+}
+
+ASD_EXPORT int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* weight, int64_t ld_w, int dtype, int D,
+                                  const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
+                                  float inv_temperature, float* lp_target, uint8_t* accept, int32_t* n_acc,
+                                  uint64_t* accept_bits, void* workspace, size_t workspace_bytes, void* stream) {
+    return asd_lm_head_verify_ex(hidden, ld_h, weight, ld_w, dtype, D, tok, lp_draft, u, B, K, V, inv_temperature, 0,
+                                 lp_target, accept, n_acc, accept_bits, nullptr, workspace, workspace_bytes, stream);
 }

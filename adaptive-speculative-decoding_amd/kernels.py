@@ -171,12 +171,17 @@ class LmHeadVerifier:
         n = int(_lib().asd_lm_head_verify_workspace_bytes(self.B, self.K, self.V))
         self.workspace = torch.empty(max(n, 256), dtype=torch.uint8, device=weight.device)
 
-    def __call__(self, hidden: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
-                 out: Optional[VerifyResult] = None, inv_temperature: float = 1.0) -> VerifyResult:
-        """hidden [B, K, D] (or [B*K, D]) bf16: the final-norm output the lm_head would consume."""
+    def __call__(self, hidden: torch.Tensor, tok: torch.Tensor, lp_draft: Optional[torch.Tensor] = None,
+                 u: Optional[torch.Tensor] = None, out: Optional[VerifyResult] = None, inv_temperature: float = 1.0,
+                 greedy: bool = False, argmax_out: Optional[torch.Tensor] = None) -> VerifyResult:
+        """hidden [B, K, D] (or [B*K, D]) bf16: the final-norm output the lm_head would consume.
+        greedy=True: accept[b,k] = (tok[b,k] == argmax logits[b,k]) (lp_draft / u unused);
+        argmax_out: optional [B, K] int32 tensor that receives the row arg-max either way."""
         Bv, K = tok.shape
         if (Bv, K) != (self.B, self.K):
             raise ValueError(f"verifier was sized for B={self.B}, K={self.K}, got {Bv}, {K}")
+        if not greedy and (lp_draft is None or u is None):
+            raise ValueError("lp_draft and u are required unless greedy=True")
         h2 = hidden.reshape(Bv * K, hidden.shape[-1]) if hidden.dim() == 3 else hidden
         if h2.dtype != torch.bfloat16 or h2.shape != (Bv * K, self.D) or h2.stride(1) != 1:
             raise ValueError("hidden must be [B*K, D] bf16 with contiguous rows")
@@ -186,13 +191,14 @@ class LmHeadVerifier:
                                torch.empty((Bv, K), dtype=torch.uint8, device=dev),
                                torch.empty((Bv,), dtype=torch.int32, device=dev),
                                torch.empty((Bv,), dtype=torch.int64, device=dev))
-        rc = _lib().asd_lm_head_verify(h2.data_ptr(), h2.stride(0) if Bv * K > 1 else self.D, self.weight.data_ptr(),
-                                       self.weight.stride(0), B.DTYPE_BF16, self.D, _dev(tok, "tok", torch.int32),
-                                       _dev(lp_draft, "lp_draft", torch.float32), _dev(u, "u", torch.float32), Bv, K,
-                                       self.V, float(inv_temperature), out.lp_target.data_ptr(), out.accept.data_ptr(),
-                                       out.n_acc.data_ptr(), out.accept_bits.data_ptr(), self.workspace.data_ptr(),
-                                       self.workspace.numel(), _stream())
-        B.check("asd_lm_head_verify", rc)
+        rc = _lib().asd_lm_head_verify_ex(h2.data_ptr(), h2.stride(0) if Bv * K > 1 else self.D, self.weight.data_ptr(),
+                                          self.weight.stride(0), B.DTYPE_BF16, self.D, _dev(tok, "tok", torch.int32),
+                                          _opt(lp_draft, "lp_draft", torch.float32), _opt(u, "u", torch.float32), Bv, K,
+                                          self.V, float(inv_temperature), 1 if greedy else 0, out.lp_target.data_ptr(),
+                                          out.accept.data_ptr(), out.n_acc.data_ptr(), out.accept_bits.data_ptr(),
+                                          _opt(argmax_out, "argmax_out", torch.int32), self.workspace.data_ptr(),
+                                          self.workspace.numel(), _stream())
+        B.check("asd_lm_head_verify_ex", rc)
         return out
 
 

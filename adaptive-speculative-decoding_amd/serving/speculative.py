@@ -217,7 +217,7 @@ class RaggedTrace:
 def speculative_generate_ragged(draft, target, prompt_ids: torch.Tensor, max_new_tokens: int,
                                 verifier: SpeculativeVerifier, *, temperature: float = 1.0, seed: int = 0,
                                 feat: Optional[torch.Tensor] = None, keep_inputs: bool = False,
-                                sync_every: int = 4) -> RaggedTrace:
+                                sync_every: int = 4, greedy_hidden: bool = False) -> RaggedTrace:
     """The loop with per-sequence lengths: every sequence commits ITS n_acc + 1 tokens per
     step (no lock-step minimum), both KV caches are per-sequence and rolling back after a rejection is the
     length update asd_commit_step does on the device.  The host reads nothing back inside a step; it looks
@@ -226,7 +226,13 @@ def speculative_generate_ragged(draft, target, prompt_ids: torch.Tensor, max_new
     Invariant at the top of a step, L = seq_len[b]: tokens[b, :L] are committed; the target's KV is valid
     for positions < L - 1 and the draft's for positions < L - 2 (at least), so the target is fed
     [t_{L-1}, d_0 .. d_{K-1}] at position L - 1 (row i scores d_i, row K is the bonus row) and the draft first
-    re-feeds the last two committed tokens."""
+    re-feeds the last two committed tokens.
+
+    greedy_hidden=True is greedy decoding with a target tier that never forms logits (N2 + N3): the draft
+    proposes its arg-max tokens, the target hands over the K + 1 hidden rows, asd_lm_head_verify_ex accepts
+    where the draft token IS the target's arg-max and reports every row's arg-max, and the token after the
+    accepted prefix is argmax[b, n_acc[b]] (row K, whose draft slot holds -1, is the bonus row).  The output
+    equals the target's own greedy continuation."""
     dev = prompt_ids.device
     gen = torch.Generator(device=dev).manual_seed(seed)
     B, P = prompt_ids.shape
@@ -247,6 +253,7 @@ def speculative_generate_ragged(draft, target, prompt_ids: torch.Tensor, max_new
     if P > 2:
         draft.forward_ragged(prompt_ids[:, :P - 2], zero, P)
     rows = torch.arange(B, device=dev)
+    gv = g_arg = None
     masks, inputs, commits = [], [], []
     verified = torch.zeros((), dtype=torch.int64, device=dev)
     steps = 0
@@ -257,7 +264,10 @@ def speculative_generate_ragged(draft, target, prompt_ids: torch.Tensor, max_new
         dl = draft.forward_ragged(last2, L - 2, window)[:, -1]
         toks, lps, dls = [], [], []
         for k in range(Kd):
-            t, lp = _sample(dl, temperature, gen)
+            if greedy_hidden:
+                t, lp = dl.argmax(-1), torch.zeros((B,), device=dev)
+            else:
+                t, lp = _sample(dl, temperature, gen)
             toks.append(t)
             lps.append(lp)
             dls.append(dl)
@@ -265,6 +275,27 @@ def speculative_generate_ragged(draft, target, prompt_ids: torch.Tensor, max_new
                 dl = draft.forward_ragged(t[:, None], L + k, window)[:, -1]
         tok = torch.stack(toks, 1)
         lp_d = torch.stack(lps, 1).contiguous()
+        if greedy_hidden:
+            hid = target.forward_ragged(torch.cat([last2[:, 1:], tok], 1), L - 1, window, return_hidden=True)   # [B, K+1, D]
+            tok_pad = torch.cat([tok.to(torch.int32), torch.full((B, 1), -1, dtype=torch.int32, device=dev)], 1).contiguous()
+            if gv is None:
+                gv = K.LmHeadVerifier(target.lm_head.weight, B, Kd + 1)
+                g_arg = torch.empty((B, Kd + 1), dtype=torch.int32, device=dev)
+            vr = gv(hid, tok_pad, greedy=True, argmax_out=g_arg, inv_temperature=target.logit_scale)
+            drawn = g_arg.gather(1, vr.n_acc.to(torch.int64)[:, None])[:, 0].contiguous()
+            tok32 = tok_pad[:, :Kd].contiguous()
+            K.commit_step(tok32, vr.n_acc, drawn, seq_len, tokens, n_commit, max_len=cap)
+            verified += n_commit.sum()
+            masks.append(vr.accept[:, :Kd].clone())
+            commits.append(n_commit.clone())
+            if keep_inputs:
+                inputs.append(dict(tok=tok32.clone(), n_acc=vr.n_acc.clone(), drawn=drawn.clone(), argmax=g_arg.clone()))
+            steps += 1
+            if steps % sync_every == 0 and int(seq_len.min().item()) >= cap:
+                break
+            if steps > max_new_tokens + sync_every:
+                raise RuntimeError("ragged loop did not terminate")
+            continue
         t_out = target.forward_ragged(torch.cat([last2[:, 1:], tok], 1), L - 1, window)     # [B, K+1, V]
         score = t_out[:, :Kd].contiguous()
         u = torch.rand((B, Kd), generator=gen, device=dev)

@@ -143,6 +143,17 @@ int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* weight, int
                        const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
                        float inv_temperature, float* lp_target, uint8_t* accept, int32_t* n_acc,
                        uint64_t* accept_bits, void* workspace, size_t workspace_bytes, void* stream);
+/* The same call with the row arg-max: argmax_out[b,k] = argmin-id argmax_v logits[b,k,v] (ties -> lowest id,
+ * NaN logits never win, -1 if the row has no logit > -inf; may be NULL).  greedy != 0 replaces the sampling
+ * test by greedy verification, accept[b,k] = (tok[b,k] == argmax_out[b,k]); lp_draft and u are then unused
+ * (may be NULL) and lp_target is still the draft token's log-prob under the target.  With the arg-max a
+ * hidden-state tier needs no logits row for greedy decoding: the correction token after the accepted
+ * prefix is argmax_out[b, n_acc[b]], the bonus token the arg-max of an extra row. */
+int asd_lm_head_verify_ex(const void* hidden, int64_t ld_h, const void* weight, int64_t ld_w, int dtype, int D,
+                          const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
+                          float inv_temperature, int greedy, float* lp_target, uint8_t* accept, int32_t* n_acc,
+                          uint64_t* accept_bits, int32_t* argmax_out /*[B,K] out, may be NULL*/,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * N3  commit / KV rollback bookkeeping of one token-level step, on the device.

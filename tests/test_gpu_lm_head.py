@@ -240,3 +240,76 @@ def test_token_logprobs_from_hidden():
     np.testing.assert_allclose(got, exact, rtol=0, atol=LMH_ATOL)
     scored = token_logprobs((h.float() @ w.float().T), tok)       # the reference-shaped call on materialised f32 scores
     np.testing.assert_allclose(got, scored, rtol=0, atol=LMH_ATOL)
+
+
+@pytest.mark.parametrize("B,K,D,V", [(3, 5, 64, 300), (32, 8, 256, 4173), (2, 7, 128, 66000)])
+def test_lm_head_argmax_and_greedy_verification(B, K, D, V):
+    """asd_lm_head_verify_ex: the row arg-max and greedy accept (tok == argmax).  The arg-max is compared
+    where the f64 top-2 gap exceeds the f32 accumulation error (ties / near-ties are a coin flip for any
+    finite-precision GEMM); on those rows it must be exact, and the greedy mask follows from it."""
+    import torch
+
+    from asd_amd import kernels as Kn
+
+    case = make_case(B, K, D, V, seed=7 * B + K)
+    x = case["ref"]["logits64"].reshape(B * K, V)
+    top2 = np.partition(x, V - 2, axis=1)[:, V - 2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-3
+    assert clear.mean() > 0.9
+    am_ref = x.argmax(axis=1).astype(np.int32)
+    tok = case["tok"].copy().reshape(-1)
+    tok[::3] = am_ref[::3]                                   # make a third of the draft tokens the arg-max
+    tok = tok.reshape(B, K)
+    w, h = bf16_dev(case["wb"]), bf16_dev(case["hb"])
+    ver = Kn.LmHeadVerifier(w, B, K)
+    am = torch.full((B, K), -7, dtype=torch.int32, device="cuda")
+    r = ver(h, torch.from_numpy(tok).cuda(), greedy=True, argmax_out=am)
+    torch.cuda.synchronize()
+    am_gpu = am.cpu().numpy().reshape(-1)
+    assert np.array_equal(am_gpu[clear], am_ref[clear])
+    acc = r.accept.cpu().numpy().reshape(-1)
+    assert np.array_equal(acc, (tok.reshape(-1) == am_gpu).astype(np.uint8))      # the mask is the kernel's own arg-max test
+    n_acc_ref = np.array([int(np.argmin(np.append(a, 0))) for a in acc.reshape(B, K)], dtype=np.int32)
+    assert np.array_equal(r.n_acc.cpu().numpy(), n_acc_ref)
+    ref = O.lm_head_verify(case["hb"], case["wb"], tok, np.zeros((B, K), np.float32), np.ones((B, K), np.float32), B, K)
+    np.testing.assert_allclose(r.lp_target.cpu().numpy(), ref["lp_t64"], rtol=0, atol=LMH_ATOL)   # lp is still reported
+    # the sampling call reports the same arg-max
+    am2 = torch.empty_like(am)
+    ver(h, torch.from_numpy(tok).cuda(), torch.from_numpy(case["lp_d"]).cuda(), torch.from_numpy(case["u"]).cuda(), argmax_out=am2)
+    torch.cuda.synchronize()
+    assert torch.equal(am, am2)
+
+
+def test_greedy_loop_without_target_logits_reproduces_target_greedy_decoding():
+    """N2 + N3 end to end: greedy speculative decoding where the target tier only ever hands over hidden
+    states.  Teacher-forced check: at every generated position the committed token is the arg-max of the
+    target's f32 logits given the committed prefix (positions whose top-2 gap is below 1e-2 are skipped)."""
+    import torch
+
+    from asd_amd.serving import synthetic_lm as SL
+    from asd_amd.serving.speculative import SpeculativeVerifier, speculative_generate_ragged
+
+    B, K, V, P, NEW = 4, 4, 1000, 5, 20
+    target = SL.SyntheticLM(SL.tiny(vocab=V, hidden=128, layers=2), device="cuda", seed=1, logit_scale=4.0)
+    draft = SL.SyntheticLM(SL.tiny(vocab=V, hidden=128, layers=2), device="cuda", seed=1, logit_scale=4.0)
+    with torch.no_grad():                                   # a draft that agrees with the target most of the time
+        for pd in draft.parameters():
+            pd.add_(torch.randn_like(pd) * 0.01 * pd.abs().mean())
+    g = torch.Generator(device="cuda").manual_seed(2)
+    prompt = torch.randint(0, V, (B, P), device="cuda", generator=g)
+    tr = speculative_generate_ragged(draft, target, prompt, NEW, SpeculativeVerifier(B, K, V), greedy_hidden=True,
+                                     keep_inputs=True, sync_every=2)
+    assert (tr.seq_len.cpu().numpy() == P + NEW).all()
+    toks = tr.tokens.to(torch.int64)
+    target.reset()
+    hid = target(toks[:, :-1], return_hidden=True)                         # dense forward over the committed text
+    logits = hid.float() @ target.lm_head.weight.float().T
+    top2 = logits.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-2
+    pred = logits.argmax(-1)                                               # pred[:, t] = greedy token at position t + 1
+    gen_pos = torch.arange(P - 1, P + NEW - 1, device="cuda")
+    ok = clear[:, gen_pos]
+    assert ok.float().mean().item() > 0.8
+    assert torch.equal(pred[:, gen_pos][ok], toks[:, P:][ok])
+    assert tr.steps < NEW                                                  # the draft got tokens accepted
+    assert sum(int(m.sum().item()) for m in tr.accept_masks) > 0
