@@ -45,6 +45,7 @@ SIGNATURES = {
                                 _sz, _vp]),
     "asd_lm_head_verify_ex": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _sz, _vp]),
+    "asd_lm_head_partial": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
     "asd_commit_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),
     "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
     "asd_mlp_packed_floats": (_sz, [_i, _i]),

@@ -60,6 +60,7 @@ struct LmHeadParams {
     float c2;
     float* msg;          // [blocks of both launches][M][kMsg]
     int m_blocks;
+    int v_offset;        // global vocabulary id of column 0 (a vocabulary shard of a tensor-parallel lm_head)
     int col0;            // first vocabulary column of this launch
     int unit0;           // index of this launch's first block in msg (one triple per row and block)
 };
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + 64 * wm + 32 * mt + r;
-        const int tk = (wave_works && m < p.M) ? p.tok[m] : -1;
+        const int tk = (wave_works && m < p.M && p.tok[m] >= p.v_offset) ? p.tok[m] - p.v_offset : -1;
         float m2 = kSentinel, s = 0.0f, g = -INFINITY, bv = -INFINITY;
         int bi = kNoIndex;
         if (wave_works) {
@@ -278,10 +279,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
 // takes draft positions w, w + waves, ...; its lanes stride over the blocks (fixed order: deterministic).
 // greedy != 0: accept[b,k] = (tok[b,k] == argmax_v logits[b,k,v]) instead of the sampling test
 // (lp_d / u unused); argmax_out (may be NULL) receives the row arg-max either way (-1: no finite logit).
+// emit != NULL: write the merged (m2, s, g) per row ([B,K,3], the asd_lse_partial message) and stop there.
 __global__ __launch_bounds__(1024) void k_accept_from_blocks(const float* msg, int n_blocks, const float* lp_d,
                                                             const float* u, const int32_t* tok, int greedy, int B, int K,
                                                             float c2, float* lp_t, uint8_t* accept, int32_t* n_acc,
-                                                            uint64_t* bits, int32_t* argmax_out) {
+                                                            uint64_t* bits, int32_t* argmax_out, float* emit) {
     __shared__ float red[ASD_MAX_DRAFT_LEN][3];
     __shared__ int best[ASD_MAX_DRAFT_LEN];
     const int b = blockIdx.x;
@@ -320,6 +322,15 @@ __global__ __launch_bounds__(1024) void k_accept_from_blocks(const float* msg, i
     }
     __syncthreads();
     if (w != 0) return;
+    if (emit) {   // vocabulary shard of a tensor-parallel lm_head: hand the merged (m2, s, g) to the all-gather
+        if (lane < K) {
+            float* out = emit + (static_cast<int64_t>(b) * K + lane) * 3;
+            out[0] = red[lane][0];
+            out[1] = red[lane][1];
+            out[2] = red[lane][2];
+        }
+        return;
+    }
     bool flag = false;
     if (lane < K) {
         const int64_t row = static_cast<int64_t>(b) * K + lane;
@@ -348,38 +359,46 @@ ASD_EXPORT size_t asd_lm_head_verify_workspace_bytes(int B, int K, int V) {
     return round_up(static_cast<size_t>(max_blocks_for(V)) * static_cast<size_t>(B) * K * kMsg * sizeof(float), 256);
 }
 
-ASD_EXPORT int asd_lm_head_verify_ex(const void* hidden, int64_t ld_h, const void* weight, int64_t ld_w, int dtype, int D,
-                                     const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
-                                     float inv_temperature, int greedy, float* lp_target, uint8_t* accept,
-                                     int32_t* n_acc, uint64_t* accept_bits, int32_t* argmax_out, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-    if (B < 0 || K < 0 || V < 1 || D < 1) return ASD_ERR_INVALID_ARG;
-    if (!(inv_temperature > 0.0f) || !(inv_temperature < 3.0e38f)) return ASD_ERR_INVALID_ARG;
-    if (B == 0 || K == 0) return ASD_OK;
-    if (K > ASD_MAX_DRAFT_LEN) return ASD_ERR_UNSUPPORTED;
-    if (dtype != ASD_DTYPE_BF16 || D % kSuper != 0) return ASD_ERR_UNSUPPORTED;
-    if (!hidden || !weight || !tok || !lp_target || !accept || !n_acc) return ASD_ERR_INVALID_ARG;
-    if (!greedy && (!lp_draft || !u)) return ASD_ERR_INVALID_ARG;
-    if (ld_h < D || ld_w < D) return ASD_ERR_INVALID_ARG;
-    if (!aligned_to(hidden, 16) || !aligned_to(weight, 16) || ld_h % 8 != 0 || ld_w % 8 != 0) return ASD_ERR_ALIGNMENT;
-    if (!workspace || workspace_bytes < asd_lm_head_verify_workspace_bytes(B, K, V)) return ASD_ERR_WORKSPACE;
-    if (!aligned_to(workspace, 16)) return ASD_ERR_ALIGNMENT;
+namespace {
+struct LmHeadCall {
+    const void* hidden; int64_t ld_h; const void* weight; int64_t ld_w; int dtype, D;
+    const int32_t* tok; const float* lp_draft; const float* u; int B, K, V; int64_t v_offset; float inv_temperature;
+    int greedy; float* lp_target; uint8_t* accept; int32_t* n_acc; uint64_t* accept_bits; int32_t* argmax_out;
+    float* emit; void* workspace; size_t workspace_bytes; void* stream;
+};
 
-    const int64_t M = static_cast<int64_t>(B) * K;
+int lm_head_launch(const LmHeadCall& c) {
+    if (c.B < 0 || c.K < 0 || c.V < 1 || c.D < 1 || c.v_offset < 0) return ASD_ERR_INVALID_ARG;
+    if (!(c.inv_temperature > 0.0f) || !(c.inv_temperature < 3.0e38f)) return ASD_ERR_INVALID_ARG;
+    if (c.B == 0 || c.K == 0) return ASD_OK;
+    if (c.K > ASD_MAX_DRAFT_LEN) return ASD_ERR_UNSUPPORTED;
+    if (c.dtype != ASD_DTYPE_BF16 || c.D % kSuper != 0 || c.v_offset + c.V >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
+    if (!c.hidden || !c.weight || !c.tok) return ASD_ERR_INVALID_ARG;
+    if (c.emit == nullptr) {
+        if (!c.lp_target || !c.accept || !c.n_acc) return ASD_ERR_INVALID_ARG;
+        if (!c.greedy && (!c.lp_draft || !c.u)) return ASD_ERR_INVALID_ARG;
+    }
+    if (c.ld_h < c.D || c.ld_w < c.D) return ASD_ERR_INVALID_ARG;
+    if (!aligned_to(c.hidden, 16) || !aligned_to(c.weight, 16) || c.ld_h % 8 != 0 || c.ld_w % 8 != 0) return ASD_ERR_ALIGNMENT;
+    if (!c.workspace || c.workspace_bytes < asd_lm_head_verify_workspace_bytes(c.B, c.K, c.V)) return ASD_ERR_WORKSPACE;
+    if (!aligned_to(c.workspace, 16)) return ASD_ERR_ALIGNMENT;
+
+    const int64_t M = static_cast<int64_t>(c.B) * c.K;
     const int64_t m_blocks = (M + kBM - 1) / kBM;
-    if (M >= (1ll << 31) || m_blocks * max_blocks_for(V) >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
+    if (M >= (1ll << 31) || m_blocks * max_blocks_for(c.V) >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
     // 256-column blocks while they fill whole rounds of the CUs, 128-column blocks for the rest
     const int64_t cus = current_device_cus();
-    const int64_t wide = (static_cast<int64_t>(V / 256) * m_blocks / cus) * cus / m_blocks;
+    const int64_t wide = (static_cast<int64_t>(c.V / 256) * m_blocks / cus) * cus / m_blocks;
     const int tail_col = static_cast<int>(wide * 256);
-    const int64_t narrow = (static_cast<int64_t>(V) - tail_col + 127) / 128;
+    const int64_t narrow = (static_cast<int64_t>(c.V) - tail_col + 127) / 128;
     LmHeadParams p{};
-    p.hidden = hidden; p.ld_h = ld_h; p.weight = weight; p.ld_w = ld_w;
-    p.D = D; p.M = static_cast<int>(M); p.V = V; p.tok = tok;
-    p.c2 = static_cast<float>(1.4426950408889634074 * static_cast<double>(inv_temperature));
-    p.msg = static_cast<float*>(workspace);
+    p.hidden = c.hidden; p.ld_h = c.ld_h; p.weight = c.weight; p.ld_w = c.ld_w;
+    p.D = c.D; p.M = static_cast<int>(M); p.V = c.V; p.tok = c.tok;
+    p.v_offset = static_cast<int>(c.v_offset);
+    p.c2 = static_cast<float>(1.4426950408889634074 * static_cast<double>(c.inv_temperature));
+    p.msg = static_cast<float*>(c.workspace);
     p.m_blocks = static_cast<int>(m_blocks);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStream_t st = static_cast<hipStream_t>(c.stream);
     if (wide > 0) {
         p.col0 = 0;
         p.unit0 = 0;
@@ -390,10 +409,21 @@ ASD_EXPORT int asd_lm_head_verify_ex(const void* hidden, int64_t ld_h, const voi
         p.unit0 = static_cast<int>(wide);
         hipLaunchKernelGGL(k_lm_head_tile<2>, dim3(static_cast<unsigned>(narrow * m_blocks)), dim3(kThreads), 0, st, p);
     }
-    hipLaunchKernelGGL(k_accept_from_blocks, dim3(B), dim3(64 * (K < 16 ? K : 16)), 0, st, p.msg,
-                       static_cast<int>(wide + narrow), lp_draft, u, tok, greedy ? 1 : 0, B, K, p.c2, lp_target, accept,
-                       n_acc, accept_bits, argmax_out);
+    hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
+                       static_cast<int>(wide + narrow), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
+                       c.lp_target, c.accept, c.n_acc, c.accept_bits, c.argmax_out, c.emit);
     return launch_status();
+}
+}  // namespace
+
+ASD_EXPORT int asd_lm_head_verify_ex(const void* hidden, int64_t ld_h, const void* weight, int64_t ld_w, int dtype, int D,
+                                     const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
+                                     float inv_temperature, int greedy, float* lp_target, uint8_t* accept,
+                                     int32_t* n_acc, uint64_t* accept_bits, int32_t* argmax_out, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    return lm_head_launch(LmHeadCall{hidden, ld_h, weight, ld_w, dtype, D, tok, lp_draft, u, B, K, V, 0, inv_temperature,
+                                     greedy, lp_target, accept, n_acc, accept_bits, argmax_out, nullptr, workspace,
+                                     workspace_bytes, stream});
 }
 
 ASD_EXPORT int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* weight, int64_t ld_w, int dtype, int D,
@@ -402,4 +432,14 @@ ASD_EXPORT int asd_lm_head_verify(const void* hidden, int64_t ld_h, const void* 
                                   uint64_t* accept_bits, void* workspace, size_t workspace_bytes, void* stream) {
     return asd_lm_head_verify_ex(hidden, ld_h, weight, ld_w, dtype, D, tok, lp_draft, u, B, K, V, inv_temperature, 0,
                                  lp_target, accept, n_acc, accept_bits, nullptr, workspace, workspace_bytes, stream);
+}
+
+ASD_EXPORT int asd_lm_head_partial(const void* hidden, int64_t ld_h, const void* weight_shard, int64_t ld_w, int dtype,
+                                   int D, const int32_t* tok, int B, int K, int V_shard, int64_t v_offset,
+                                   float inv_temperature, float* msg, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    if (B > 0 && K > 0 && !msg) return ASD_ERR_INVALID_ARG;
+    return lm_head_launch(LmHeadCall{hidden, ld_h, weight_shard, ld_w, dtype, D, tok, nullptr, nullptr, B, K, V_shard,
+                                     v_offset, inv_temperature, 0, nullptr, nullptr, nullptr, nullptr, nullptr, msg,
+                                     workspace, workspace_bytes, stream});
 }

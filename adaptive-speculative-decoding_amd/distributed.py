@@ -61,6 +61,14 @@ class HipOps:
         r = self.K.accept_from_partials(msg_all, lp_d, u, inv_temperature=inv_temperature)
         return r.lp_target, r.accept, r.n_acc, r.accept_bits
 
+    def lm_head_partial(self, hidden, weight_shard, tok, v_offset, inv_temperature: float = 1.0):
+        B, K = tok.shape
+        key = ("lmh", weight_shard.data_ptr(), B, K)
+        ver = self._ws.get(key)
+        if ver is None:
+            ver = self._ws[key] = self.K.LmHeadVerifier(weight_shard, B, K)
+        return ver.partial(hidden, tok, v_offset, inv_temperature)
+
 
 def _world(group) -> Tuple[int, int]:
     return dist.get_world_size(group), dist.get_rank(group)
@@ -83,6 +91,19 @@ class VocabShardedVerifier:
         if logits_shard.shape[-1] != self.v1 - self.v0:
             raise ValueError(f"rank {self.rank} expects a shard of width {self.v1 - self.v0}")
         msg = self.ops.lse_partial(logits_shard, tok, self.v0, self.inv_temperature).contiguous()
+        return self._finish(msg, lp_d, u)
+
+    def verify_hidden(self, hidden: torch.Tensor, weight_shard: torch.Tensor, tok: torch.Tensor, lp_d: torch.Tensor,
+                      u: torch.Tensor):
+        """Tensor-parallel lm_head (N2): `weight_shard` [v1-v0, D] is THIS rank's rows of the lm_head matrix,
+        `hidden` [B,K,D] is replicated.  Each rank reduces its shard to the (m2, s, g) message without forming
+        logits (asd_lm_head_partial); the exchange and the result are those of `verify`."""
+        if weight_shard.shape[0] != self.v1 - self.v0:
+            raise ValueError(f"rank {self.rank} expects a weight shard of {self.v1 - self.v0} rows")
+        msg = self.ops.lm_head_partial(hidden, weight_shard, tok, self.v0, self.inv_temperature).contiguous()
+        return self._finish(msg, lp_d, u)
+
+    def _finish(self, msg, lp_d, u):
         parts = [torch.empty_like(msg) for _ in range(self.world)]
         dist.all_gather(parts, msg, group=self.group)          # the one exchange step: [B,K,3] per rank
         return self.ops.accept_from_partials(torch.stack(parts).contiguous(), lp_d, u, self.inv_temperature)

@@ -202,6 +202,26 @@ class LmHeadVerifier:
         return out
 
 
+    def partial(self, hidden: torch.Tensor, tok: torch.Tensor, v_offset: int, inv_temperature: float = 1.0,
+                msg: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`self.weight` is this rank's vocabulary shard starting at global id `v_offset`: returns the
+        [B, K, 3] (m2, s, g) message of asd_lse_partial without forming the shard's logits (asd_lm_head_partial)."""
+        Bv, K = tok.shape
+        if (Bv, K) != (self.B, self.K):
+            raise ValueError(f"verifier was sized for B={self.B}, K={self.K}, got {Bv}, {K}")
+        h2 = hidden.reshape(Bv * K, hidden.shape[-1]) if hidden.dim() == 3 else hidden
+        if h2.dtype != torch.bfloat16 or h2.shape != (Bv * K, self.D) or h2.stride(1) != 1:
+            raise ValueError("hidden must be [B*K, D] bf16 with contiguous rows")
+        if msg is None:
+            msg = torch.empty((Bv, K, 3), dtype=torch.float32, device=h2.device)
+        rc = _lib().asd_lm_head_partial(h2.data_ptr(), h2.stride(0) if Bv * K > 1 else self.D, self.weight.data_ptr(),
+                                        self.weight.stride(0), B.DTYPE_BF16, self.D, _dev(tok, "tok", torch.int32), Bv, K,
+                                        self.V, int(v_offset), float(inv_temperature), _dev(msg, "msg", torch.float32),
+                                        self.workspace.data_ptr(), self.workspace.numel(), _stream())
+        B.check("asd_lm_head_partial", rc)
+        return msg
+
+
 def commit_step(tok: torch.Tensor, n_acc: torch.Tensor, drawn: torch.Tensor, seq_len: torch.Tensor,
                 out_tokens: torch.Tensor, n_commit: Optional[torch.Tensor] = None, max_len: Optional[int] = None) -> None:
     """N3: append every sequence's accepted prefix + drawn token to its row of `out_tokens` and advance

@@ -155,6 +155,15 @@ int asd_lm_head_verify_ex(const void* hidden, int64_t ld_h, const void* weight, 
                           uint64_t* accept_bits, int32_t* argmax_out /*[B,K] out, may be NULL*/,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Tensor-parallel lm_head (weight split over ranks along the vocabulary): this rank's [V_shard, D] slice,
+ * whose row 0 is global vocabulary id v_offset, reduced straight to the asd_lse_partial message
+ * msg[b,k,:] = (m2, s, g); all-gather the messages and finish with asd_accept_from_partials.  The
+ * logits of the shard are never formed; [B,K,3] floats per rank is the only exchange. */
+int asd_lm_head_partial(const void* hidden, int64_t ld_h, const void* weight_shard, int64_t ld_w, int dtype, int D,
+                        const int32_t* tok /*[B,K] GLOBAL ids*/, int B, int K, int V_shard, int64_t v_offset,
+                        float inv_temperature, float* msg /*[B,K,3] out*/, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * N3  commit / KV rollback bookkeeping of one token-level step, on the device.
  * The reference's src/serving/cache_manager.py:149-190 `truncate_at_stage` trims a dict of strings;

@@ -80,6 +80,13 @@ class OracleOps:
         msg[..., 0] /= np.log(2.0)
         return torch.from_numpy(msg)
 
+    def lm_head_partial(self, hidden, weight_shard, tok, v_offset, inv_temperature=1.0):
+        """f64 product of the bf16 operands, then the shard message of lse_partial on those logits."""
+        import torch
+        x = hidden.double().reshape(-1, hidden.shape[-1]) @ weight_shard.double().T
+        B, K = tok.shape
+        return self.lse_partial(x.float().reshape(B, K, -1), tok, v_offset, inv_temperature)
+
     def accept_from_partials(self, msg_all, lp_d, u, inv_temperature=1.0):
         import torch
         m = msg_all.numpy().astype(np.float64)

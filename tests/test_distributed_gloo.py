@@ -48,6 +48,23 @@ def _worker(rank, world, port, what, ret):
             assert np.array_equal(bits.numpy().view(np.uint64), ref["bits"])
             with pytest.raises(ValueError):
                 v.verify(lg, tok, lp_d, u)
+        elif what == "vocab_hidden":
+            # tensor-parallel lm_head: hidden states replicated, weight rows split; only [B,K,3] crosses the link
+            g = torch.Generator().manual_seed(5)
+            Dm = 64
+            hid = torch.randn((B, K, Dm), generator=g).to(torch.bfloat16)
+            wgt = (torch.randn((V, Dm), generator=g) * (3.0 / Dm ** 0.5)).to(torch.bfloat16)
+            hb = hid.reshape(B * K, Dm).view(torch.int16).numpy().view(np.uint16)
+            wb = wgt.view(torch.int16).numpy().view(np.uint16)
+            from oracle import oracle as O
+            full = O.lm_head_verify(hb, wb, tok.numpy(), lp_d.numpy(), u.numpy(), B, K)
+            v = D.VocabShardedVerifier(V, ops=OracleOps())
+            lp, acc, n_acc, bits = v.verify_hidden(hid, wgt[v.v0:v.v1].contiguous(), tok, lp_d, u)
+            np.testing.assert_allclose(lp.numpy(), full["lp_t64"], atol=2e-5, rtol=1e-6)
+            safe = full["margin"] >= 1e-4
+            assert np.array_equal(acc.numpy()[safe], full["accept"][safe])
+            with pytest.raises(ValueError):
+                v.verify_hidden(hid, wgt, tok, lp_d, u)
         elif what == "batch":
             v = D.BatchShardedVerifier(B, ops=OracleOps())
             s = slice(v.b0, v.b1)
@@ -104,7 +121,7 @@ def _worker(rank, world, port, what, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("what", ["vocab", "batch", "tiers", "tier_loop"])
+@pytest.mark.parametrize("what", ["vocab", "vocab_hidden", "batch", "tiers", "tier_loop"])
 def test_two_rank_gloo(what):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:

@@ -313,3 +313,31 @@ def test_greedy_loop_without_target_logits_reproduces_target_greedy_decoding():
     assert torch.equal(pred[:, gen_pos][ok], toks[:, P:][ok])
     assert tr.steps < NEW                                                  # the draft got tokens accepted
     assert sum(int(m.sum().item()) for m in tr.accept_masks) > 0
+
+
+def test_lm_head_partial_shards_combine_to_the_full_call():
+    """asd_lm_head_partial: two vocabulary shards (ragged split) reduced separately, stacked like an
+    all-gather and finished with asd_accept_from_partials, against the oracle and the unsharded call."""
+    import torch
+
+    from asd_amd import kernels as Kn
+    from asd_amd.distributed import shard_bounds
+
+    B, K, D, V = 6, 8, 128, 5001
+    case = make_case(B, K, D, V, seed=21, inv_t=1.0 / 0.8)
+    w, h = bf16_dev(case["wb"]), bf16_dev(case["hb"])
+    tok = torch.from_numpy(case["tok"]).cuda()
+    lp_d, u = torch.from_numpy(case["lp_d"]).cuda(), torch.from_numpy(case["u"]).cuda()
+    msgs = []
+    for rank in range(3):
+        v0, v1 = shard_bounds(V, 3, rank)
+        shard = w[v0:v1]                                    # a view: rows stay 16-byte aligned (D = 128)
+        msgs.append(Kn.LmHeadVerifier(shard, B, K).partial(h, tok, v0, inv_temperature=case["inv_t"]))
+    r = Kn.accept_from_partials(torch.stack(msgs).contiguous(), lp_d, u, inv_temperature=case["inv_t"])
+    full = Kn.LmHeadVerifier(w, B, K)(h, tok, lp_d, u, inv_temperature=case["inv_t"])
+    torch.cuda.synchronize()
+    got = dict(lp_t=r.lp_target.cpu().numpy(), accept=r.accept.cpu().numpy(), n_acc=r.n_acc.cpu().numpy(),
+               bits=r.accept_bits.cpu().numpy().view(np.uint64))
+    check(got, case["ref"])
+    assert (r.lp_target - full.lp_target).abs().max().item() < 1e-5
+    assert torch.equal(r.accept, full.accept)
