@@ -8,9 +8,9 @@
 // (v_mfma_f32_32x32x16_bf16 with the WEIGHT tile as the A operand, so a lane holds 16 vocabulary entries
 // of ONE row and the row reduction is lane-local).  At the end the accumulators are folded into the
 // log2-domain partial (m2, s) of lse_device.hpp, logit[tok] is gathered where the block owns it, and the
-// (m2, s, g) triple asd_lse_partial emits for a vocabulary shard is written per 64-column unit.
-// k_accept_from_blocks merges the units of every row and applies the accept rule (finish_row /
-// finish_sequence: the code the streaming kernel ends in).
+// record (m2, s, g, arg-max value, arg-max id) of the block is written per row -- (m2, s, g) is the message
+// asd_lse_partial emits for a vocabulary shard.  k_accept_from_blocks merges the blocks' records of every
+// row and applies the accept rule (finish_row / finish_sequence: the code the streaming kernel ends in).
 //
 // Data movement, per 64 reduction columns ("superstage"):
 // Both operands move as whole 128-byte lines by LDS-DMA (global_load_lds_dwordx4: 8 lanes per row, no
@@ -62,7 +62,7 @@ struct LmHeadParams {
     int m_blocks;
     int v_offset;        // global vocabulary id of column 0 (a vocabulary shard of a tensor-parallel lm_head)
     int col0;            // first vocabulary column of this launch
-    int unit0;           // index of this launch's first block in msg (one triple per row and block)
+    int unit0;           // index of this launch's first block in msg (one record per row and block)
 };
 
 template <int PENDING>
