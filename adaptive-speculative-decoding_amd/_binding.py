@@ -55,6 +55,7 @@ SIGNATURES = {
     "asd_bayes_adjust": (_i, [_vp, _i64, _d, _d, _i, _vp, _vp]),
     "asd_optimal_stopping": (_i, [_vp, _vp, _d, _i, _i, _i, _d, _d, _vp, _vp, _vp]),
     "asd_expected_cost": (_i, [_vp, _vp, _d, _vp, _i, _i, _vp, _vp]),
+    "asd_lambda_sweep": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp]),
     "asd_derive_thresholds": (_i, [_vp, _vp, _i, _d, _vp, _vp]),
     "asd_predictor_stop": (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d,
                                 _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

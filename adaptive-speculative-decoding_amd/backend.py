@@ -75,6 +75,19 @@ class HipBackend:
         return K.expected_cost(self._up(p, np.float64), self._up(Cc, np.float64), lam,
                                self._up(np.asarray(k).reshape(-1), np.int32)).cpu().numpy()
 
+    # -- N4
+    def lambda_sweep(self, p, Cc, lam, risk_adjustment=False, alpha=1.0, beta=1.0):
+        from . import kernels as K
+
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        Cc = np.ascontiguousarray(Cc, dtype=np.float64).reshape(-1)
+        if p.shape[1] != Cc.size:
+            raise ValueError("p and C must have the same length")
+        k, cost, ok = K.lambda_sweep(self._up(p, np.float64), self._up(Cc, np.float64),
+                                     self._up(np.ascontiguousarray(lam, dtype=np.float64).reshape(-1), np.float64),
+                                     risk_adjustment, alpha, beta)
+        return k.cpu().numpy(), cost.cpu().numpy(), ok.cpu().numpy()
+
     # -- A10
     def derive_thresholds(self, q, c, lam) -> np.ndarray:
         from . import kernels as K

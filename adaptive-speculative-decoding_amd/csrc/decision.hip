@@ -47,6 +47,37 @@ __global__ void k_optimal_stopping(const double* __restrict__ p, const double* _
     }
 }
 
+// N4: the DP rule for a whole grid of lambda values -- one thread per (lambda, request).  p_ok multiplies
+// left to right like compute_expected_cost (dp_solver.py:92-95), cost adds left to right like sum(C[:k+1]).
+__global__ void k_lambda_sweep(const double* __restrict__ p, const double* __restrict__ C, const double* __restrict__ lam,
+                               int B, int L, int G, int risk, double alpha, double beta, int32_t* __restrict__ k_star,
+                               double* __restrict__ cost, double* __restrict__ p_ok) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<int64_t>(G) * B) return;
+    const int g = static_cast<int>(i / B);
+    const int b = static_cast<int>(i % B);
+    double pp[ASD_MAX_STAGES], cc[ASD_MAX_STAGES], Jb[ASD_MAX_STAGES + 1];
+#pragma unroll
+    for (int s = 0; s < ASD_MAX_STAGES; ++s) {
+        if (s < L) {
+            pp[s] = p[static_cast<int64_t>(b) * L + s];
+            cc[s] = C[s];
+        }
+    }
+    const int ks = optimal_stopping1(pp, cc, lam[g], L, risk, alpha, beta, Jb);
+    double pb = 1.0, cs = 0.0;
+#pragma unroll
+    for (int s = 0; s < ASD_MAX_STAGES; ++s) {
+        if (s <= ks) {
+            pb *= pp[s];
+            cs += cc[s];
+        }
+    }
+    k_star[i] = ks;
+    if (cost) cost[i] = cs;
+    if (p_ok) p_ok[i] = pb;
+}
+
 __global__ void k_expected_cost(const double* __restrict__ p, const double* __restrict__ C, double lam,
                                 const int32_t* __restrict__ k, int B, int L, double* __restrict__ cost) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,6 +125,20 @@ ASD_EXPORT int asd_optimal_stopping(const double* p, const double* C, double lam
     if (!p || !C || !k_star) return ASD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_optimal_stopping, grid_for(B, 64), dim3(64), 0, static_cast<hipStream_t>(stream), p, C, lam,
                        B, L, risk_adjustment ? 1 : 0, alpha, beta, k_star, J);
+    return launch_status();
+}
+
+ASD_EXPORT int asd_lambda_sweep(const double* p, const double* C, const double* lam, int B, int L, int G,
+                                int risk_adjustment, double alpha, double beta, int32_t* k_star, double* cost,
+                                double* p_ok, void* stream) {
+    if (B < 0 || G < 0 || L < 1) return ASD_ERR_INVALID_ARG;
+    if (L > ASD_MAX_STAGES) return ASD_ERR_UNSUPPORTED;
+    if (B == 0 || G == 0) return ASD_OK;
+    if (!p || !C || !lam || !k_star) return ASD_ERR_INVALID_ARG;
+    const int64_t n = static_cast<int64_t>(G) * B;
+    if (n >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_lambda_sweep, grid_for(static_cast<int>(n), 64), dim3(64), 0, static_cast<hipStream_t>(stream), p,
+                       C, lam, B, L, G, risk_adjustment ? 1 : 0, alpha, beta, k_star, cost, p_ok);
     return launch_status();
 }
 

@@ -309,6 +309,21 @@ def optimal_stopping(p: torch.Tensor, Cc: torch.Tensor, lam: float, risk_adjustm
     return k, J
 
 
+def lambda_sweep(p: torch.Tensor, Cc: torch.Tensor, lam: torch.Tensor, risk_adjustment: bool = False, alpha: float = 1.0,
+                 beta: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """N4: p [B,L] f64, Cc [L] f64, lam [G] f64 -> (k_star [G,B] i32, cost [G,B] f64, p_ok [G,B] f64)."""
+    Bv, L = p.shape
+    G = lam.shape[0]
+    k = torch.empty((G, Bv), dtype=torch.int32, device=p.device)
+    cost = torch.empty((G, Bv), dtype=torch.float64, device=p.device)
+    ok = torch.empty((G, Bv), dtype=torch.float64, device=p.device)
+    rc = _lib().asd_lambda_sweep(_dev(p, "p", torch.float64), _dev(Cc, "C", torch.float64), _dev(lam, "lam", torch.float64),
+                                 Bv, L, G, 1 if risk_adjustment else 0, float(alpha), float(beta), k.data_ptr(),
+                                 cost.data_ptr(), ok.data_ptr(), _stream())
+    B.check("asd_lambda_sweep", rc)
+    return k, cost, ok
+
+
 def expected_cost(p: torch.Tensor, Cc: torch.Tensor, lam: float, k: torch.Tensor) -> torch.Tensor:
     """A3 batched."""
     Bv, L = p.shape

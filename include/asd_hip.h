@@ -226,6 +226,16 @@ int asd_expected_cost(const double* p /*[B,L]*/, const double* C /*[L]*/, double
                       const int32_t* k /*[B]*/, int B, int L, double* cost /*[B] out*/,
                       void* stream);
 
+/* N4  the DP rule over a GRID of lambda values in one launch: what a lambda controller
+ * (src/algorithms/optimizer.py:47-205 LambdaOptimizer, :261-335 GridSearchOptimizer) needs per candidate
+ * when requests are described by their predicted stage probabilities.  For every lam[g] and request b:
+ *   k_star[g,b]  optimal_stopping_rule(p[b], C, lam[g], risk_adjustment, alpha, beta)      (dp_solver.py:12-71)
+ *   cost[g,b]    sum(C[:k*+1]),   p_ok[g,b] = prod(p[b,:k*+1])     (the two terms of compute_expected_cost,
+ *                dp_solver.py:74-103: expected cost = cost + lam * (1 - p_ok)).  cost / p_ok may be NULL. */
+int asd_lambda_sweep(const double* p /*[B,L]*/, const double* C /*[L]*/, const double* lam /*[G]*/,
+                     int B, int L, int G, int risk_adjustment, double alpha, double beta,
+                     int32_t* k_star /*[G,B]*/, double* cost /*[G,B]*/, double* p_ok /*[G,B]*/, void* stream);
+
 /* A10  OptimalStoppingTheory.derive_optimal_policy, src/theory/optimal_stopping.py:45-82
  * (+ _compute_improvement_probability :84-91).  HOST pointers: an O(n) f64 recursion run once
  * per set_lambda; theta[n] (theta[n-1] = 0), V[n+1] (may be NULL). */

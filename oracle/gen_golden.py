@@ -292,6 +292,79 @@ def gen_a4(dp, rng):
                        fresh_explore=bool(fresh.should_explore(2))), f, indent=1)
 
 
+def _stage_model(dp, P, C, ms_per_cost):
+    """evaluate_function(lam) -> (latency_ms, quality) of a request population described by its predicted
+    stage probabilities: every request runs the reference DP rule, latency = mean cost * ms_per_cost,
+    quality = mean probability that the stage it stops at is accepted (reference functions only)."""
+    def evaluate(lam):
+        lat, qual = [], []
+        for p in P:
+            k, _ = dp.optimal_stopping_rule(list(p), list(C), float(lam))
+            ok = 1.0
+            for i in range(k + 1):
+                ok *= p[i]
+            lat.append(sum(C[:k + 1]) * ms_per_cost)
+            qual.append(ok)
+        return float(np.mean(lat)), float(np.mean(qual))
+    return evaluate
+
+
+def gen_optimizer(dp, rng):
+    """N4: src/algorithms/optimizer.py (LambdaOptimizer, GridSearchOptimizer) driven by the DP rule."""
+    opt = _load("src.algorithms.optimizer", os.path.join(SRC, "algorithms", "optimizer.py"))
+    B, L = 96, 4
+    P = np.sort(rng.uniform(0.2, 1.0, (B, L)), axis=1)
+    P[:, -1] = 1.0
+    C = [1.0, 1.6, 4.2, 8.8]
+    lam = np.concatenate([np.logspace(-2, 2, 20), [0.0, 3.3, 250.0]])
+    ks = np.zeros((lam.size, B), np.int32)
+    cost = np.zeros((lam.size, B))
+    ok = np.zeros((lam.size, B))
+    tot = np.zeros((lam.size, B))
+    for g, lv in enumerate(lam):
+        for b in range(B):
+            k, _ = dp.optimal_stopping_rule(list(P[b]), C, float(lv))
+            pb = 1.0
+            for i in range(k + 1):
+                pb *= P[b, i]
+            ks[g, b], cost[g, b], ok[g, b] = k, sum(C[:k + 1]), pb
+            tot[g, b] = dp.compute_expected_cost(list(P[b]), C, float(lv), k)
+    np.savez(os.path.join(OUT, "lambda_sweep.npz"), p=P, C=np.array(C), lam=lam, k_star=ks, cost=cost, p_ok=ok,
+             expected_cost=tot)
+    ev = _stage_model(dp, P, C, 100.0)
+    out = dict(ms_per_cost=100.0, latency=[], pareto=[], balanced=[])
+    for cons in (150.0, 400.0, 900.0, 50.0):
+        r = opt.LambdaOptimizer(latency_constraint=cons).optimize_for_latency_constraint(ev)
+        out["latency"].append(dict(constraint=cons, optimal_lambda=r.optimal_lambda, achieved_latency=r.achieved_latency,
+                                   achieved_quality=r.achieved_quality, constraint_satisfied=bool(r.constraint_satisfied),
+                                   iterations=int(r.iterations)))
+    out["pareto"] = [list(map(float, t)) for t in opt.LambdaOptimizer(lambda_bounds=(0.05, 50.0)).optimize_pareto_front(ev, 12)]
+    for w in (0.5, 0.9):
+        r = opt.LambdaOptimizer().find_balanced_lambda(ev, quality_weight=w)
+        out["balanced"].append(dict(quality_weight=w, optimal_lambda=float(r.optimal_lambda),
+                                    achieved_latency=r.achieved_latency, achieved_quality=r.achieved_quality,
+                                    iterations=int(r.iterations)))
+    # an analytic population whose latency FALLS with lambda (the monotonicity the bisection assumes)
+    def analytic(lam):
+        return 2000.0 / (1.0 + lam) + 40.0, 1.0 / (1.0 + 0.3 * lam)
+    out["analytic"] = dict(latency=[], balanced=[])
+    for cons, tol, iters in ((150.0, 1e-3, 50), (400.0, 1e-6, 50), (900.0, 1e-3, 5), (30.0, 1e-3, 50)):
+        r = opt.LambdaOptimizer(latency_constraint=cons).optimize_for_latency_constraint(analytic, tolerance=tol,
+                                                                                         max_iterations=iters)
+        out["analytic"]["latency"].append(dict(constraint=cons, tolerance=tol, max_iterations=iters,
+                                               optimal_lambda=r.optimal_lambda, achieved_latency=r.achieved_latency,
+                                               achieved_quality=r.achieved_quality,
+                                               constraint_satisfied=bool(r.constraint_satisfied), iterations=int(r.iterations)))
+    for w in (0.3, 0.7):
+        r = opt.LambdaOptimizer(lambda_bounds=(0.1, 20.0)).find_balanced_lambda(analytic, quality_weight=w)
+        out["analytic"]["balanced"].append(dict(quality_weight=w, optimal_lambda=float(r.optimal_lambda),
+                                                achieved_latency=r.achieved_latency, achieved_quality=r.achieved_quality,
+                                                iterations=int(r.iterations)))
+    out["analytic"]["pareto"] = [list(map(float, t)) for t in opt.LambdaOptimizer().optimize_pareto_front(analytic, 7)]
+    with open(os.path.join(OUT, "lambda_optimizer.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     dp, th, mad = load_reference()
@@ -303,6 +376,7 @@ def main():
     gen_features_a7(rng)
     gen_logprob_idiom(rng)
     gen_a4(dp, rng)
+    gen_optimizer(dp, np.random.default_rng(4321))
     print("wrote", sorted(os.listdir(OUT)))
 
 

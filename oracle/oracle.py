@@ -196,6 +196,27 @@ def lm_head_verify(hidden_bits: np.ndarray, weight_bits: np.ndarray, tok, lp_d, 
     return dict(lp_t64=lp, accept=acc, n_acc=n_acc, bits=bits, margin=margin, logits64=x.reshape(B, K, V))
 
 
+def lambda_sweep(p, Cc, lam, risk_adjustment: bool = False, alpha: float = 1.0, beta: float = 1.0):
+    """N4 oracle: the DP rule (C restatement, pinned by dp_rule.npz) per lambda, then sum C[:k*+1] and
+    prod p[:k*+1] left to right like dp_solver.py:92-98.  Returns (k_star [G,B] i32, cost [G,B], p_ok [G,B])."""
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    Cc = np.ascontiguousarray(Cc, dtype=np.float64).reshape(-1)
+    lam = np.ascontiguousarray(lam, dtype=np.float64).reshape(-1)
+    B, L = p.shape
+    ks = np.zeros((lam.size, B), np.int32)
+    cost = np.zeros((lam.size, B))
+    ok = np.zeros((lam.size, B))
+    for g, lv in enumerate(lam):
+        ks[g], _ = optimal_stopping(p, Cc, float(lv), risk_adjustment, alpha, beta)
+        for b in range(B):
+            pb, cs = 1.0, 0.0
+            for i in range(int(ks[g, b]) + 1):
+                pb *= p[b, i]
+                cs += Cc[i]
+            cost[g, b], ok[g, b] = cs, pb
+    return ks, cost, ok
+
+
 def commit_step(tok, n_acc, drawn, seq_len, out_tokens, max_len: Optional[int] = None):
     """N3 oracle (numpy, integer): returns (new seq_len, new out_tokens, n_commit); inputs are not modified."""
     tok = np.asarray(tok, dtype=np.int32)

@@ -23,6 +23,9 @@ class OracleBackend:
     def derive_thresholds(self, q, c, lam):
         return O.derive_thresholds(q, c, lam)[0]
 
+    def lambda_sweep(self, p, Cc, lam, risk_adjustment=False, alpha=1.0, beta=1.0):
+        return O.lambda_sweep(p, Cc, lam, risk_adjustment, alpha, beta)
+
     def mlp_predict(self, x, w1, b1, w2, b2):
         return O.mlp_predict(x, w1, b1, np.asarray(w2).reshape(-1), b2)
 

@@ -3,6 +3,8 @@ reference's own files: bit-exact.  Called through the C ABI on device tensors.""
 import numpy as np
 import pytest
 
+from oracle import oracle as O
+
 pytestmark = pytest.mark.gpu
 
 
@@ -115,3 +117,30 @@ def test_reference_signature_functions_on_gpu(golden):
     L = int(d["L"][i])
     assert compute_expected_cost(list(d["p"][i, :L]), list(d["C"][i, :L]), float(d["lam"][i]),
                                  int(d["k_star"][i])) == float(d["cost_at_kstar"][i])
+
+
+def test_lambda_sweep_bit_exact(golden):
+    """N4: asd_lambda_sweep -- k*, sum C[:k*+1] and prod p[:k*+1] for every (lambda, request) in one launch --
+    against the reference's optimal_stopping_rule / compute_expected_cost outputs (f64, bit for bit)."""
+    import torch
+    from asd_amd import kernels as K
+    g = golden.npz("lambda_sweep.npz")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    k, cost, ok = K.lambda_sweep(dev(g["p"]), dev(g["C"]), dev(g["lam"]))
+    torch.cuda.synchronize()
+    assert np.array_equal(k.cpu().numpy(), g["k_star"])
+    assert cost.cpu().numpy().tobytes() == g["cost"].tobytes()
+    assert ok.cpu().numpy().tobytes() == g["p_ok"].tobytes()
+    # risk-adjusted variant against the oracle (which is pinned by dp_rule.npz)
+    k2, c2, o2 = K.lambda_sweep(dev(g["p"]), dev(g["C"]), dev(g["lam"]), risk_adjustment=True, alpha=2.0, beta=3.0)
+    rk, rc, ro = O.lambda_sweep(g["p"], g["C"], g["lam"], True, 2.0, 3.0)
+    assert np.array_equal(k2.cpu().numpy(), rk) and c2.cpu().numpy().tobytes() == rc.tobytes()
+    assert o2.cpu().numpy().tobytes() == ro.tobytes()
+    # the controllers on the real backend give the recorded reference results
+    import asd_amd
+    from asd_amd.algorithms import LambdaOptimizer, StagePopulation
+    asd_amd.set_backend(None)
+    ref = golden.json("lambda_optimizer.json")
+    pop = StagePopulation(g["p"], g["C"], ms_per_cost=ref["ms_per_cost"])
+    front = LambdaOptimizer(lambda_bounds=(0.05, 50.0)).optimize_pareto_front(pop.evaluate, 12)
+    assert [list(map(float, t)) for t in front] == ref["pareto"]

@@ -413,3 +413,47 @@ def test_ragged_kv_forward_equals_full_context_and_survives_rollback():
         lo = int(pos0[b])
         torch.testing.assert_close(out[b], full[b, lo:lo + T], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(a, full[:, :5], rtol=1e-4, atol=1e-5)
+
+
+def test_lambda_controllers_match_reference_results(golden, oracle_backend):
+    """N4: LambdaOptimizer on the same evaluate functions as the reference run recorded in the goldens."""
+    from asd_amd.algorithms import LambdaOptimizer, StagePopulation
+
+    ref = golden.json("lambda_optimizer.json")
+    g = golden.npz("lambda_sweep.npz")
+    pop = StagePopulation(g["p"], g["C"], ms_per_cost=ref["ms_per_cost"])
+    for row in ref["latency"]:
+        r = LambdaOptimizer(latency_constraint=row["constraint"]).optimize_for_latency_constraint(pop.evaluate)
+        assert (r.optimal_lambda, r.achieved_latency, r.achieved_quality, r.constraint_satisfied, r.iterations) == \
+            (row["optimal_lambda"], row["achieved_latency"], row["achieved_quality"], row["constraint_satisfied"], row["iterations"])
+    front = LambdaOptimizer(lambda_bounds=(0.05, 50.0)).optimize_pareto_front(pop.evaluate, 12)
+    assert [list(map(float, t)) for t in front] == ref["pareto"]
+    for row in ref["balanced"]:
+        r = LambdaOptimizer().find_balanced_lambda(pop.evaluate, quality_weight=row["quality_weight"])
+        assert abs(r.optimal_lambda - row["optimal_lambda"]) <= 1e-9 * max(1.0, row["optimal_lambda"])
+        assert (r.achieved_latency, r.achieved_quality, r.iterations) == (row["achieved_latency"], row["achieved_quality"], row["iterations"])
+
+    def analytic(lam):
+        return 2000.0 / (1.0 + lam) + 40.0, 1.0 / (1.0 + 0.3 * lam)
+    a = ref["analytic"]
+    for row in a["latency"]:
+        r = LambdaOptimizer(latency_constraint=row["constraint"]).optimize_for_latency_constraint(
+            analytic, tolerance=row["tolerance"], max_iterations=row["max_iterations"])
+        assert (r.optimal_lambda, r.achieved_latency, r.achieved_quality, r.constraint_satisfied, r.iterations) == \
+            (row["optimal_lambda"], row["achieved_latency"], row["achieved_quality"], row["constraint_satisfied"], row["iterations"])
+    for row in a["balanced"]:
+        r = LambdaOptimizer(lambda_bounds=(0.1, 20.0)).find_balanced_lambda(analytic, quality_weight=row["quality_weight"])
+        assert abs(r.optimal_lambda - row["optimal_lambda"]) <= 1e-9 * row["optimal_lambda"] and r.iterations == row["iterations"]
+    assert [list(map(float, t)) for t in LambdaOptimizer().optimize_pareto_front(analytic, 7)] == a["pareto"]
+    with pytest.raises(ValueError):
+        LambdaOptimizer().optimize_for_latency_constraint(analytic)
+
+
+def test_grid_search_population_table(oracle_backend, golden):
+    from asd_amd.algorithms import GridSearchOptimizer, StagePopulation
+    g = golden.npz("lambda_sweep.npz")
+    pop = StagePopulation(g["p"], g["C"], ms_per_cost=100.0)
+    t = GridSearchOptimizer(lambda_grid=[float(v) for v in g["lam"]]).search_population(pop)
+    assert t["costs"] == [float(np.mean(c)) for c in g["cost"]]
+    assert t["stage_distributions"][-1] == np.bincount(g["k_star"][-1], minlength=4).tolist()
+    assert len(t["latencies"]) == len(g["lam"]) and t["latencies"][0] == t["costs"][0] * 100.0

@@ -152,3 +152,13 @@ def test_verify_accept_c_vs_numpy_small():
     for b in range(B):
         w = sum(int(res["accept"][b, k]) << k for k in range(K))
         assert int(res["bits"][b]) == w
+
+
+def test_lambda_sweep_oracle_matches_reference(golden):
+    """N4: the oracle's lambda sweep against the reference's optimal_stopping_rule / compute_expected_cost."""
+    g = golden.npz("lambda_sweep.npz")
+    k, cost, ok = O.lambda_sweep(g["p"], g["C"], g["lam"])
+    assert np.array_equal(k, g["k_star"])
+    assert cost.tobytes() == g["cost"].tobytes() and ok.tobytes() == g["p_ok"].tobytes()
+    total = cost + g["lam"][:, None] * (1 - ok)                     # compute_expected_cost, dp_solver.py:95-101
+    assert total.tobytes() == g["expected_cost"].tobytes()
