@@ -67,7 +67,9 @@ struct LmHeadParams {
 
 template <int PENDING>
 __device__ __forceinline__ void wait_and_meet() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PENDING) : "memory");
+    // lgkmcnt(0): this wave's LDS reads (the fragments it carries across the barrier) have returned, so the
+    // slots it read may be refilled by anyone once the barrier is passed
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PENDING) : "memory");
 }
 
 template <int NTW>   // 32-column accumulator tiles per wave: 4 (256-column block) or 2 (128-column block)
@@ -141,67 +143,84 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     const int key = (r >> 1) & 7;
     const int h_off = (64 * wm + r) * 128;
     const int w_off = (32 * NTW * wn + r) * 128;
-    // The fragment reads of k-step ks + 1 are issued before the MFMAs of k-step ks (two register sets);
-    // the sched_barriers pin that order -- left alone the scheduler emits read, read, wait, mfma, mfma.
-    auto compute = [&](int S) {
-        if (!wave_works) return;
+    // The fragment reads of k-step ks + 1 are issued before the MFMAs of k-step ks (two register sets; the
+    // sched_barriers pin that order -- left alone the scheduler emits read, read, wait, mfma, mfma).  The LAST
+    // k-step of a superstage is multiplied only after the next barrier: its fragments are in registers by
+    // then, so the MFMA pipe has work while the wave issues the DMA of the coming superstages and waits for
+    // the first fragments of the next one (the barrier -> first MFMA bubble was ~12 % of an iteration).
+    bf16x8 wf[2][NTW], hf[2][2];
+    auto read_frags = [&](int S, int ks, int set) {
         const unsigned char* wb = lds + (S % kWRing) * kWSlot + w_off;
         const unsigned char* hb = lds_h + (S & (kHRing - 1)) * kHSlot + h_off;
-        bf16x8 wf[2][NTW], hf[2][2];
-        auto read_frags = [&](int ks) {
-            const int so = ((4 * h + ks) ^ key) * 16;
+        const int so = ((4 * h + ks) ^ key) * 16;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) hf[ks & 1][mt] = *reinterpret_cast<const bf16x8*>(hb + mt * 32 * 128 + so);
+        for (int mt = 0; mt < 2; ++mt) hf[set][mt] = *reinterpret_cast<const bf16x8*>(hb + mt * 32 * 128 + so);
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) wf[ks & 1][nt] = *reinterpret_cast<const bf16x8*>(wb + nt * 32 * 128 + so);
-        };
-        read_frags(0);
+        for (int nt = 0; nt < NTW; ++nt) wf[set][nt] = *reinterpret_cast<const bf16x8*>(wb + nt * 32 * 128 + so);
+    };
+    auto multiply = [&](int set) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);   // MFMA issue ahead of the other wave's reads / DMA issue: -10 % (7B head)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < 4) read_frags(ks + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);   // MFMA issue ahead of the other wave's reads / DMA issue: -10 % (7B head)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], hf[ks & 1][mt], acc[mt][nt], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
+            for (int nt = 0; nt < NTW; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], hf[set][mt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
+    // k-steps 0..2 of superstage S are multiplied; the fragments of k-step 3 are left in register set 1
+    auto head = [&](int S) {
+        if (!wave_works) return;
+        read_frags(S, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(S, 1, 1);
+        multiply(0);
+        read_frags(S, 2, 0);
+        multiply(1);
+        read_frags(S, 3, 1);
+        multiply(0);
+    };
+    auto tail = [&]() {
+        if (wave_works) multiply(1);
+    };
 
-    // Issue order per iteration S: hidden(S+1) x HPASSES, then weights(S+2) x WPASSES.  At the top of
-    // iteration S the youngest loads are therefore  hidden(S), weights(S+1) : vmcnt(WPASSES) retires this
-    // wave's share of hidden(S) and of everything older (weights(S)) and leaves weights(S+1) in flight; the
-    // barrier then makes every wave's share visible.  The slots refilled after the barrier (hidden: the one
-    // read in S-1; weights: slot (S+2) % 3 = (S-1) % 3) were last read before their readers reached it.
+    // Issue order: prologue W(0), H(0), W(1); after the barrier that opens superstage S: H(S+1), W(S+2).
+    // At that barrier the youngest loads are  H(S), W(S+1) : vmcnt(WPASSES) retires this wave's share of H(S)
+    // and of everything older (W(S)) and leaves W(S+1) in flight; the barrier makes every wave's share visible.
+    // The slots refilled after it (hidden: slot of S-1; weights: slot (S+2) % 3 = (S-1) % 3) were read into
+    // registers -- k-step 3 included, see wait_and_meet's lgkmcnt(0) -- before their readers reached it.
     issue_w(0);
     issue_h(0);
     if (n_super > 1) issue_w(1);
     int S = 0;
     for (; S + 2 < n_super; ++S) {   // steady state: branch-free
         wait_and_meet<WPASSES>();
+#if !(ASD_LMHEAD_LAB & 2)
+        if (S > 0) tail();           // k-step 3 of superstage S-1
+#endif
 #if !(ASD_LMHEAD_LAB & 1)
         issue_h(S + 1);
         issue_w(S + 2);
 #endif
 #if !(ASD_LMHEAD_LAB & 2)
-        compute(S);
+        head(S);
 #endif
     }
     for (; S < n_super; ++S) {       // the last two superstages
-        if (S + 1 < n_super) {
-            wait_and_meet<WPASSES>();
-            issue_h(S + 1);
-        } else {
-            wait_and_meet<0>();
-        }
+        if (S + 1 < n_super) wait_and_meet<WPASSES>();
+        else wait_and_meet<0>();
 #if !(ASD_LMHEAD_LAB & 2)
-        compute(S);
+        if (S > 0) tail();
+#endif
+        if (S + 1 < n_super) issue_h(S + 1);
+#if !(ASD_LMHEAD_LAB & 2)
+        head(S);
 #endif
     }
+#if !(ASD_LMHEAD_LAB & 2)
+    tail();                          // k-step 3 of the last superstage
+#endif
     // ---- epilogue: D[vocab row][m column]; lane (r, h) holds row m and, per 32-column tile, the 16
     // vocabulary ids  n = tile + (i & 3) + 8 * (i >> 2) + 4 * h.  A wave folds its 32 * NTW columns per row,
     // the two wave columns meet in LDS (free now: every DMA was retired by the last wait), and the block
