@@ -60,6 +60,7 @@ struct LmHeadParams {
     float c2;
     float* msg;          // [blocks of both launches][M][kMsg]
     int m_blocks;
+    int n_blocks;        // column blocks of this launch
     int v_offset;        // global vocabulary id of column 0 (a vocabulary shard of a tensor-parallel lm_head)
     int col0;            // first vocabulary column of this launch
     int unit0;           // index of this launch's first block in msg (one record per row and block)
@@ -88,9 +89,23 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     const int wn = wv >> 2;    // wave column: weight rows 32 * NTW * wn ..
     const int r = lane & 31;
     const int h = lane >> 5;
-    // consecutive workgroups share a weight tile (its re-read for M > 256 stays close in time)
-    const int mb = static_cast<int>(blockIdx.x) % p.m_blocks;
-    const int nb = static_cast<int>(blockIdx.x) / p.m_blocks;
+    // M > 256: the row blocks that share a weight tile get ids 8 apart, i.e. the same XCD (workgroups are
+    // dealt round-robin to the 8 XCDs) and the same dispatch round: one of them pulls the tile from HBM,
+    // the others find it in that XCD's L2.  Column blocks past the last multiple of 8 keep the plain order.
+    int mb, nb;
+    {
+        const int id = static_cast<int>(blockIdx.x);
+        const int group = 8 * p.m_blocks;
+        const int swizzled = (p.n_blocks / 8) * group;
+        if (id < swizzled) {
+            const int in_group = id % group;
+            nb = (id / group) * 8 + in_group % 8;
+            mb = in_group / 8;
+        } else {
+            mb = (id - swizzled) % p.m_blocks;
+            nb = (p.n_blocks / 8) * 8 + (id - swizzled) / p.m_blocks;
+        }
+    }
     const int n0 = p.col0 + nb * BN;
     const int m0 = mb * kBM;
     const int rows_w = min(BN, p.V - n0);
@@ -421,11 +436,13 @@ int lm_head_launch(const LmHeadCall& c) {
     if (wide > 0) {
         p.col0 = 0;
         p.unit0 = 0;
+        p.n_blocks = static_cast<int>(wide);
         hipLaunchKernelGGL(k_lm_head_tile<4>, dim3(static_cast<unsigned>(wide * m_blocks)), dim3(kThreads), 0, st, p);
     }
     if (narrow > 0) {
         p.col0 = tail_col;
         p.unit0 = static_cast<int>(wide);
+        p.n_blocks = static_cast<int>(narrow);
         hipLaunchKernelGGL(k_lm_head_tile<2>, dim3(static_cast<unsigned>(narrow * m_blocks)), dim3(kThreads), 0, st, p);
     }
     hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
