@@ -73,13 +73,15 @@ __device__ __forceinline__ void wait_and_meet() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PENDING) : "memory");
 }
 
-template <int NTW>   // 32-column accumulator tiles per wave: 4 (256-column block) or 2 (128-column block)
+// NTW: 32-column accumulator tiles per wave: 4 (256-column block) or 2 (128-column block).
+// HPASSES: 64-row DMA passes over the hidden rows, ceil(rows / 64) for a call with M <= 256 rows (1, 2 or 4):
+// at M = 64 three quarters of the hidden-state traffic into LDS would be padding.
+template <int NTW, int HPASSES>
 __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     constexpr int BN = 64 * NTW;             // 2 wave columns
     constexpr int kWSlot = BN * 128;         // one weight superstage
     constexpr int kHSlot = kBM * 128;        // one hidden superstage
     constexpr int WPASSES = BN / 64;         // DMA instructions per thread and superstage (64 rows per pass)
-    constexpr int HPASSES = kBM / 64;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[kWRing * kWSlot + kHRing * kHSlot];
     unsigned char* const lds_h = lds + kWRing * kWSlot;
     const int t = threadIdx.x;
@@ -394,6 +396,13 @@ ASD_EXPORT size_t asd_lm_head_verify_workspace_bytes(int B, int K, int V) {
 }
 
 namespace {
+template <int NTW>
+void launch_tile(int h_passes, dim3 grid, hipStream_t st, const LmHeadParams& p) {
+    if (h_passes == 1) hipLaunchKernelGGL((k_lm_head_tile<NTW, 1>), grid, dim3(kThreads), 0, st, p);
+    else if (h_passes == 2) hipLaunchKernelGGL((k_lm_head_tile<NTW, 2>), grid, dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_lm_head_tile<NTW, 4>), grid, dim3(kThreads), 0, st, p);
+}
+
 struct LmHeadCall {
     const void* hidden; int64_t ld_h; const void* weight; int64_t ld_w; int dtype, D;
     const int32_t* tok; const float* lp_draft; const float* u; int B, K, V; int64_t v_offset; float inv_temperature;
@@ -433,17 +442,18 @@ int lm_head_launch(const LmHeadCall& c) {
     p.msg = static_cast<float*>(c.workspace);
     p.m_blocks = static_cast<int>(m_blocks);
     hipStream_t st = static_cast<hipStream_t>(c.stream);
+    const int hp = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
     if (wide > 0) {
         p.col0 = 0;
         p.unit0 = 0;
         p.n_blocks = static_cast<int>(wide);
-        hipLaunchKernelGGL(k_lm_head_tile<4>, dim3(static_cast<unsigned>(wide * m_blocks)), dim3(kThreads), 0, st, p);
+        launch_tile<4>(hp, dim3(static_cast<unsigned>(wide * m_blocks)), st, p);
     }
     if (narrow > 0) {
         p.col0 = tail_col;
         p.unit0 = static_cast<int>(wide);
         p.n_blocks = static_cast<int>(narrow);
-        hipLaunchKernelGGL(k_lm_head_tile<2>, dim3(static_cast<unsigned>(narrow * m_blocks)), dim3(kThreads), 0, st, p);
+        launch_tile<2>(hp, dim3(static_cast<unsigned>(narrow * m_blocks)), st, p);
     }
     hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
                        static_cast<int>(wide + narrow), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
