@@ -116,35 +116,42 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     // DMA sources: one instruction moves 8 rows x 128 B (lane -> row lane >> 3, 16-byte segment lane & 7,
     // swizzled).  Rows past a matrix edge re-read the last valid row (their products are masked in the
     // epilogue), so no lane ever addresses outside the operands.
+    // Addresses are a block-uniform 64-bit base (+ the superstage's byte offset, scalar arithmetic) plus a
+    // loop-invariant 32-bit lane offset, so the DMA instructions take the saddr + voffset form and the loop
+    // spends no vector instructions on addressing (SQ counters: the DMA issue was ~8 % of an iteration).
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);   // wave id as a scalar: LDS destinations stay in SGPRs
     const int drow = wv * 8 + (lane >> 3);
-    const char* wsrc[WPASSES];
-    const char* hsrc[HPASSES];
+    const char* const wbase = static_cast<const char*>(p.weight) + static_cast<int64_t>(n0) * p.ld_w * 2;
+    const char* const hbase = static_cast<const char*>(p.hidden) + static_cast<int64_t>(m0) * p.ld_h * 2;
+    uint32_t woff[WPASSES], hoff[HPASSES];
 #pragma unroll
     for (int ps = 0; ps < WPASSES; ++ps) {
         const int row = ps * 64 + drow;
         const int seg = (lane & 7) ^ ((row >> 1) & 7);
-        wsrc[ps] = static_cast<const char*>(p.weight) + (static_cast<int64_t>(n0) + min(row, rows_w - 1)) * p.ld_w * 2 + seg * 16;
+        woff[ps] = static_cast<uint32_t>(min(row, rows_w - 1)) * static_cast<uint32_t>(p.ld_w * 2) + seg * 16;
     }
 #pragma unroll
     for (int ps = 0; ps < HPASSES; ++ps) {
         const int row = ps * 64 + drow;
         const int seg = (lane & 7) ^ ((row >> 1) & 7);
-        hsrc[ps] = static_cast<const char*>(p.hidden) + (static_cast<int64_t>(m0) + min(row, rows_h - 1)) * p.ld_h * 2 + seg * 16;
+        hoff[ps] = static_cast<uint32_t>(min(row, rows_h - 1)) * static_cast<uint32_t>(p.ld_h * 2) + seg * 16;
     }
     const int n_super = p.D / kSuper;
     auto issue_w = [&](int stage) {
-        const int64_t kb = static_cast<int64_t>(stage) * (kSuper * 2);
-        unsigned char* dst = lds + (stage % kWRing) * kWSlot + wv * 1024;
+        const char* src = wbase + static_cast<int64_t>(stage) * (kSuper * 2);
+        asm volatile("" : "+s"(src));   // keep the base in SGPRs: without it LLVM folds the lane offset into a 64-bit VGPR pointer
+        unsigned char* dst = lds + (stage % kWRing) * kWSlot + wv_s * 1024;
 #pragma unroll
         for (int ps = 0; ps < WPASSES; ++ps)
-            __builtin_amdgcn_global_load_lds((glb_void*)(wsrc[ps] + kb), (lds_void*)(dst + ps * 8192), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + woff[ps]), (lds_void*)(dst + ps * 8192), 16, 0, 2);
     };
     auto issue_h = [&](int stage) {
-        const int64_t kb = static_cast<int64_t>(stage) * (kSuper * 2);
-        unsigned char* dst = lds_h + (stage & (kHRing - 1)) * kHSlot + wv * 1024;
+        const char* src = hbase + static_cast<int64_t>(stage) * (kSuper * 2);
+        asm volatile("" : "+s"(src));
+        unsigned char* dst = lds_h + (stage & (kHRing - 1)) * kHSlot + wv_s * 1024;
 #pragma unroll
         for (int ps = 0; ps < HPASSES; ++ps)
-            __builtin_amdgcn_global_load_lds((glb_void*)(hsrc[ps] + kb), (lds_void*)(dst + ps * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + hoff[ps]), (lds_void*)(dst + ps * 8192), 16, 0, 0);
     };
 
     f32x16 acc[2][NTW];
