@@ -194,12 +194,17 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         __builtin_amdgcn_sched_barrier(0);
     };
     // k-steps 0..2 of superstage S are multiplied; the fragments of k-step 3 are left in register set 1
-    auto head = [&](int S) {
-        if (!wave_works) return;
+    auto head = [&](int S, auto&& late_issue) {
+        if (!wave_works) {
+            late_issue();
+            return;
+        }
         read_frags(S, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_frags(S, 1, 1);
         multiply(0);
+        late_issue();
+        __builtin_amdgcn_sched_barrier(0);
         read_frags(S, 2, 0);
         multiply(1);
         read_frags(S, 3, 1);
@@ -223,12 +228,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
 #if !(ASD_LMHEAD_LAB & 2)
         if (S > 0) tail();           // k-step 3 of superstage S-1
 #endif
-#if !(ASD_LMHEAD_LAB & 1)
+        // The two waves that share a SIMD (wave column 0 and 1) issue their DMA at different points of the
+        // iteration -- right after the barrier, and behind the first MFMA group -- so that a DMA instruction
+        // held up by a full memory pipeline never stops both of them from feeding the MFMA pipe (-1..-2.5 %;
+        // moving the second point behind k-step 1 loses 4 %).
+#if ASD_LMHEAD_LAB & 2
         issue_h(S + 1);
         issue_w(S + 2);
-#endif
-#if !(ASD_LMHEAD_LAB & 2)
-        head(S);
+#elif ASD_LMHEAD_LAB & 1
+        head(S, [] {});
+#else
+        if (wn == 0) { issue_h(S + 1); issue_w(S + 2); }
+        head(S, [&] { if (wn != 0) { issue_h(S + 1); issue_w(S + 2); } });
 #endif
     }
     for (; S < n_super; ++S) {       // the last two superstages
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
 #endif
         if (S + 1 < n_super) issue_h(S + 1);
 #if !(ASD_LMHEAD_LAB & 2)
-        head(S);
+        head(S, [] {});
 #endif
     }
 #if !(ASD_LMHEAD_LAB & 2)
