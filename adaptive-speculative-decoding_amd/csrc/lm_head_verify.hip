@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
                     const int n = n0 + 32 * NTW * wn + 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * h;
                     const float v = n < p.V ? acc[mt][nt][i] : -INFINITY;   // padded weight rows are not vocabulary
                     if (n == tk) g = v;
-                    if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
+                    if (v > bv || (v == bv && n < bi && n < p.V)) { bv = v; bi = n; }   // padding never wins a tie at -inf
                     x[i] = v;
                 }
                 float lo[8], hi[8];

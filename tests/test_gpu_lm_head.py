@@ -341,3 +341,31 @@ def test_lm_head_partial_shards_combine_to_the_full_call():
     check(got, case["ref"])
     assert (r.lp_target - full.lp_target).abs().max().item() < 1e-5
     assert torch.equal(r.accept, full.accept)
+
+
+def test_lm_head_verify_non_finite_rows():
+    """A NaN hidden row makes every logit of that row NaN: lp_t is NaN, the row is rejected and has no
+    arg-max (-1); an all-zero hidden row gives the uniform distribution (lp = -log V) and arg-max 0
+    (ties -> lowest id).  The other rows are unaffected."""
+    import torch
+
+    from asd_amd import kernels as Kn
+
+    B, K, D, V = 2, 4, 64, 333
+    case = make_case(B, K, D, V, seed=31)
+    h = bf16_dev(case["hb"]).clone()
+    h[1] = float("nan")                      # row (0, 1)
+    h[6] = 0.0                               # row (1, 2)
+    w = bf16_dev(case["wb"])
+    tok = torch.from_numpy(case["tok"]).cuda()
+    am = torch.empty((B, K), dtype=torch.int32, device="cuda")
+    r = Kn.LmHeadVerifier(w, B, K)(h, tok, torch.from_numpy(case["lp_d"]).cuda(), torch.from_numpy(case["u"]).cuda(),
+                                   argmax_out=am)
+    torch.cuda.synchronize()
+    lp = r.lp_target.cpu().numpy()
+    assert np.isnan(lp[0, 1]) and r.accept[0, 1].item() == 0 and am[0, 1].item() == -1
+    assert abs(lp[1, 2] + np.log(V)) < 1e-5 and am[1, 2].item() == 0
+    keep = np.ones((B, K), bool)
+    keep[0, 1] = keep[1, 2] = False
+    np.testing.assert_allclose(lp[keep], case["ref"]["lp_t64"][keep], rtol=0, atol=LMH_ATOL)
+    assert r.n_acc[0].item() <= 1            # the NaN row ends sequence 0's accepted prefix
