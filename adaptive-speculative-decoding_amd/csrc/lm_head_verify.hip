@@ -24,8 +24,9 @@
 // row; the LDS image is swizzled (segment ^ (row >> 1) & 7, on the DMA source address and on the fragment
 // read alike) so that ds_read_b128 is conflict-free.
 //
-// Column blocks: 256 wide while they fill whole rounds of the CUs, 128 wide for the remainder, so the last
-// round costs half a round (V = 152064 on 256 CUs: 512 + 164 blocks = 2.5 rounds instead of 3).
+// Column blocks: 256 wide while they fill whole rounds of the CUs; the remainder as 128-wide blocks (V = 152064
+// on 256 CUs: 512 + 164 blocks = 2.5 rounds instead of 3) or, for deep reductions, as 256-wide blocks cut into
+// reduction slices that meet through f32 slabs and a ticket (see the launcher).
 //
 // Algorithmic HBM bytes: V*D*2 (weights once per 256 rows) + M*D*2; flops: 2*M*D*V.
 #include "lse_device.hpp"
@@ -64,6 +65,9 @@ struct LmHeadParams {
     int v_offset;        // global vocabulary id of column 0 (a vocabulary shard of a tensor-parallel lm_head)
     int col0;            // first vocabulary column of this launch
     int unit0;           // index of this launch's first block in msg (one record per row and block)
+    int k_slices;        // > 1: every column block is cut into this many reduction slices (one workgroup each)
+    float* slabs;        // [n_blocks][k_slices][8 waves][2 * NTW * 4][64 lanes] float4: partial accumulators
+    uint32_t* tickets;   // [n_blocks], zero before the launch; the slice that draws k_slices - 1 finishes the block
 };
 
 template <int PENDING>
@@ -94,9 +98,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     // M > 256: the row blocks that share a weight tile get ids 8 apart, i.e. the same XCD (workgroups are
     // dealt round-robin to the 8 XCDs) and the same dispatch round: one of them pulls the tile from HBM,
     // the others find it in that XCD's L2.  Column blocks past the last multiple of 8 keep the plain order.
-    int mb, nb;
+    int mb, nb, slice = 0;
     {
-        const int id = static_cast<int>(blockIdx.x);
+        int id = static_cast<int>(blockIdx.x);
+        if (p.k_slices > 1) {           // the slices of a block are neighbours: they finish at about the same time
+            slice = id % p.k_slices;
+            id /= p.k_slices;
+        }
         const int group = 8 * p.m_blocks;
         const int swizzled = (p.n_blocks / 8) * group;
         if (id < swizzled) {
@@ -136,7 +144,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         const int seg = (lane & 7) ^ ((row >> 1) & 7);
         hoff[ps] = static_cast<uint32_t>(min(row, rows_h - 1)) * static_cast<uint32_t>(p.ld_h * 2) + seg * 16;
     }
-    const int n_super = p.D / kSuper;
+    // this workgroup's superstages [s_begin, n_super): all of them, or its reduction slice
+    const int total_super = p.D / kSuper;
+    const int per_slice = (total_super + p.k_slices - 1) / p.k_slices;
+    const int s_begin = p.k_slices > 1 ? min(slice * per_slice, total_super) : 0;
+    const int n_super = p.k_slices > 1 ? min(s_begin + per_slice, total_super) : total_super;
     auto issue_w = [&](int stage) {
         const char* src = wbase + static_cast<int64_t>(stage) * (kSuper * 2);
         asm volatile("" : "+s"(src));   // keep the base in SGPRs: without it LLVM folds the lane offset into a 64-bit VGPR pointer
@@ -219,14 +231,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     // and of everything older (W(S)) and leaves W(S+1) in flight; the barrier makes every wave's share visible.
     // The slots refilled after it (hidden: slot of S-1; weights: slot (S+2) % 3 = (S-1) % 3) were read into
     // registers -- k-step 3 included, see wait_and_meet's lgkmcnt(0) -- before their readers reached it.
-    issue_w(0);
-    issue_h(0);
-    if (n_super > 1) issue_w(1);
-    int S = 0;
+    int S = s_begin;
+    if (S < n_super) {
+        issue_w(S);
+        issue_h(S);
+        if (S + 1 < n_super) issue_w(S + 1);
+    }
     for (; S + 2 < n_super; ++S) {   // steady state: branch-free
         wait_and_meet<WPASSES>();
 #if !(ASD_LMHEAD_LAB & 2)
-        if (S > 0) tail();           // k-step 3 of superstage S-1
+        if (S > s_begin) tail();     // k-step 3 of superstage S-1
 #endif
         // The two waves that share a SIMD (wave column 0 and 1) issue their DMA at different points of the
         // iteration -- right after the barrier, and behind the first MFMA group -- so that a DMA instruction
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         if (S + 1 < n_super) wait_and_meet<WPASSES>();
         else wait_and_meet<0>();
 #if !(ASD_LMHEAD_LAB & 2)
-        if (S > 0) tail();
+        if (S > s_begin) tail();
 #endif
         if (S + 1 < n_super) issue_h(S + 1);
 #if !(ASD_LMHEAD_LAB & 2)
@@ -254,8 +268,65 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
 #endif
     }
 #if !(ASD_LMHEAD_LAB & 2)
-    tail();                          // k-step 3 of the last superstage
+    if (n_super > s_begin) tail();   // k-step 3 of the last superstage
 #endif
+
+    // ---- reduction slices: every slice publishes its partial accumulators; the one that draws the last
+    // ticket adds the others' and goes on to the epilogue.  Hand-off: plain 16-byte stores, every wave drains
+    // them (vmcnt), workgroup barrier, ONE agent-scope release + ticket by lane 0; the finisher acquires once,
+    // barrier, then plain loads.  The ticket word is zeroed by the launcher before every call.
+    if (p.k_slices > 1) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        constexpr int kChunks = 2 * NTW * 4;                       // float4 chunks per lane
+        const int64_t block_slabs = static_cast<int64_t>(nb) * p.k_slices;
+        auto slab = [&](int sl) {
+            return reinterpret_cast<f32x4*>(p.slabs) + ((block_slabs + sl) * 8 + wv) * (kChunks * 64) + lane;
+        };
+        {
+            f32x4* out = slab(slice);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+                        v[0] = acc[mt][nt][4 * q]; v[1] = acc[mt][nt][4 * q + 1];
+                        v[2] = acc[mt][nt][4 * q + 2]; v[3] = acc[mt][nt][4 * q + 3];
+                        out[((mt * NTW + nt) * 4 + q) * 64] = v;
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint32_t* const flag = reinterpret_cast<uint32_t*>(lds);   // the rings are idle now
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t old = __hip_atomic_fetch_add(p.tickets + nb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = old == static_cast<uint32_t>(p.k_slices - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *flag = last ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+        for (int sl = 0; sl < p.k_slices; ++sl) {
+            if (sl == slice) continue;
+            const f32x4* in = slab(sl);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = in[((mt * NTW + nt) * 4 + q) * 64];
+                        acc[mt][nt][4 * q] += v[0]; acc[mt][nt][4 * q + 1] += v[1];
+                        acc[mt][nt][4 * q + 2] += v[2]; acc[mt][nt][4 * q + 3] += v[3];
+                    }
+        }
+    }
     // ---- epilogue: D[vocab row][m column]; lane (r, h) holds row m and, per 32-column tile, the 16
     // vocabulary ids  n = tile + (i & 3) + 8 * (i >> 2) + 4 * h.  A wave folds its 32 * NTW columns per row,
     // the two wave columns meet in LDS (free now: every DMA was retired by the last wait), and the block
@@ -408,9 +479,23 @@ inline int max_blocks_for(int V) { return (V + 127) / 128; }
 
 using namespace asd;
 
+namespace {
+constexpr size_t kSlabBytes = 8 * 32 * 64 * 16;   // one 256-column block's accumulators: 256 KiB
+constexpr size_t kTicketBytes = 4096;             // up to 1024 tail blocks
+
+size_t records_bytes(int B, int K, int V) {
+    return round_up(static_cast<size_t>(max_blocks_for(V)) * static_cast<size_t>(B) * K * kMsg * sizeof(float), 256);
+}
+// reduction slices of the tail blocks never outnumber the CUs: one slab each
+size_t slab_budget() {
+    const int cus = current_device_cus();
+    return static_cast<size_t>(cus > 0 ? cus : 512) * kSlabBytes;
+}
+}  // namespace
+
 ASD_EXPORT size_t asd_lm_head_verify_workspace_bytes(int B, int K, int V) {
     if (B <= 0 || K <= 0 || V <= 0) return 0;
-    return round_up(static_cast<size_t>(max_blocks_for(V)) * static_cast<size_t>(B) * K * kMsg * sizeof(float), 256);
+    return records_bytes(B, K, V) + kTicketBytes + slab_budget();
 }
 
 namespace {
@@ -451,7 +536,20 @@ int lm_head_launch(const LmHeadCall& c) {
     const int64_t cus = current_device_cus();
     const int64_t wide = (static_cast<int64_t>(c.V / 256) * m_blocks / cus) * cus / m_blocks;
     const int tail_col = static_cast<int>(wide * 256);
-    const int64_t narrow = (static_cast<int64_t>(c.V) - tail_col + 127) / 128;
+    const int64_t rem = static_cast<int64_t>(c.V) - tail_col;
+    int64_t narrow = (rem + 127) / 128;
+    // The tail -- the columns that do not fill a whole round of 256-column blocks -- as 256-column blocks cut
+    // into reduction slices, one workgroup each, when that fills the CUs better than 128-column blocks do
+    // (V = 152064, 256 CUs: 82 blocks x 3 slices = 246 workgroups of a third of the depth instead of 164
+    // workgroups of half the width).  The slices meet through f32 slabs and a ticket per block.  Only for deep
+    // reductions (>= 24 superstages per slice): measured -3 % at D = 8192, -2 % at 5120, +0..2 % at 3584, where a
+    // slice is too short to amortise its pipeline ramp and the slab traffic.
+    const int64_t tail_tiles = (rem + 255) / 256;
+    int64_t slices = tail_tiles > 0 ? cus / tail_tiles : 0;
+    if (slices > 4) slices = 4;
+    while (slices >= 2 && c.D / kSuper < 24 * slices) --slices;   // a slice needs >= 24 superstages to pay (see below)
+    const bool split_k = m_blocks == 1 && M > 128 && slices >= 2 && tail_tiles * slices > narrow &&
+                         tail_tiles <= static_cast<int64_t>(kTicketBytes / 4);
     LmHeadParams p{};
     p.hidden = c.hidden; p.ld_h = c.ld_h; p.weight = c.weight; p.ld_w = c.ld_w;
     p.D = c.D; p.M = static_cast<int>(M); p.V = c.V; p.tok = c.tok;
@@ -459,6 +557,7 @@ int lm_head_launch(const LmHeadCall& c) {
     p.c2 = static_cast<float>(1.4426950408889634074 * static_cast<double>(c.inv_temperature));
     p.msg = static_cast<float*>(c.workspace);
     p.m_blocks = static_cast<int>(m_blocks);
+    p.k_slices = 1;
     hipStream_t st = static_cast<hipStream_t>(c.stream);
     const int hp = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
     if (wide > 0) {
@@ -467,7 +566,18 @@ int lm_head_launch(const LmHeadCall& c) {
         p.n_blocks = static_cast<int>(wide);
         launch_tile<4>(hp, dim3(static_cast<unsigned>(wide * m_blocks)), st, p);
     }
-    if (narrow > 0) {
+    if (split_k) {
+        char* const base = static_cast<char*>(c.workspace) + records_bytes(c.B, c.K, c.V);
+        p.tickets = reinterpret_cast<uint32_t*>(base);
+        p.slabs = reinterpret_cast<float*>(base + kTicketBytes);
+        if (hipMemsetAsync(p.tickets, 0, static_cast<size_t>(tail_tiles) * 4, st) != hipSuccess) return ASD_ERR_HIP;
+        p.col0 = tail_col;
+        p.unit0 = static_cast<int>(wide);
+        p.n_blocks = static_cast<int>(tail_tiles);
+        p.k_slices = static_cast<int>(slices);
+        launch_tile<4>(hp, dim3(static_cast<unsigned>(tail_tiles * slices)), st, p);
+        narrow = tail_tiles;          // blocks that wrote a record
+    } else if (narrow > 0) {
         p.col0 = tail_col;
         p.unit0 = static_cast<int>(wide);
         p.n_blocks = static_cast<int>(narrow);

@@ -86,6 +86,8 @@ def check(got, ref):
     (9, 33, 192, 129),       # K > 32, 297 rows, one column in the last block, odd superstage count
     (2, 64, 320, 257),       # K = ASD_MAX_DRAFT_LEN
     (32, 8, 128, 66000),     # wide (256-column) blocks for whole rounds of CUs + narrow blocks for the rest
+    (32, 8, 4096, 65636),    # ... and, for a deep reduction, the rest as a 256-column block cut into 2 reduction
+    (32, 8, 4608, 65700),    # slices / 3 slices (ticketed f32 slabs); the block is ragged (100 / 164 real columns)
 ])
 def test_lm_head_verify_matches_oracle(B, K, D, V):
     case = make_case(B, K, D, V, seed=B * 1000 + K)
