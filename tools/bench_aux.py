@@ -143,6 +143,36 @@ def main():
         g = gpu_us(lambda: samp(t, d, n_acc, r, bonus, 1.0, out), 100)
         record("asd_residual_sample", B, g, 2 * B * V * 2, float("nan"), float("nan"),
                "3 launches; bytes = one pass over the B target + B draft rows (second pass is L2 / MALL traffic)")
+    # ---------------- N3 commit / KV-rollback bookkeeping
+    for B in (32, 4096):
+        Kk, T = 8, 512
+        tok = torch.randint(0, 1000, (B, Kk), device=dev, dtype=torch.int32)
+        n_acc = torch.randint(0, Kk + 1, (B,), device=dev, dtype=torch.int32)
+        drawn = torch.randint(0, 1000, (B,), device=dev, dtype=torch.int32)
+        seq_len = torch.full((B,), 16, dtype=torch.int32, device=dev)
+        out_tok = torch.zeros((B, T), dtype=torch.int32, device=dev)
+        nc = torch.empty((B,), dtype=torch.int32, device=dev)
+
+        def commit():
+            seq_len.fill_(16)                              # keep the rows from filling up across repetitions
+            K.commit_step(tok, n_acc, drawn, seq_len, out_tok, nc)
+        g = gpu_us(commit, 200)
+        tn, nn_, dn = tok.cpu().numpy(), n_acc.cpu().numpy(), drawn.cpu().numpy()
+        ln, on = np.full(B, 16, np.int32), np.zeros((B, T), np.int32)
+        c = cpu_us(lambda: O.commit_step(tn, nn_, dn, ln, on), 0.5)
+        record("N3 asd_commit_step", B, g, B * (Kk * 4 + 4 + 4 + 4 + (Kk + 1) * 4 + 4), c, c / B,
+               "gpu time includes the seq_len reset fill; cpu = numpy/python oracle loop")
+    # ---------------- N4 lambda sweep
+    for B, G in ((96, 20), (65536, 64)):
+        pn = np.sort(rng.uniform(0.2, 1.0, (B, 4)), axis=1)
+        lam_n = np.logspace(-2, 2, G)
+        p_, l_ = torch.from_numpy(pn).to(dev), torch.from_numpy(lam_n).to(dev)
+        C4 = torch.tensor([1.0, 1.6, 4.2, 8.8], dtype=torch.float64, device=dev)
+        g = gpu_us(lambda: K.lambda_sweep(p_, C4, l_), 200 if B == 96 else 20)
+        nb = min(B, 96)
+        c = cpu_us(lambda: O.lambda_sweep(pn[:nb], Cn, lam_n[:4]), 0.5) * (B / nb) * (G / 4)
+        record("N4 asd_lambda_sweep", B * G, g, B * 32 + G * 8 + B * G * 20, c, py_dp,
+               f"{G} lambdas x {B} requests in one launch; cpu = oracle scaled from a {nb} x 4 sample; python idiom = one DP call")
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(dict(device=torch.cuda.get_device_name(0), rows=rows), f, indent=1)
