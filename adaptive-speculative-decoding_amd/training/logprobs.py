@@ -58,10 +58,13 @@ def token_logprobs_from_hidden(hidden, lm_head_weight, token_ids, inv_temperatur
     B, T, _ = h3.shape
     tok = torch.as_tensor(token_ids, device=h3.device).to(torch.int32).reshape(B, T)
     out = torch.empty((B, T), dtype=torch.float32, device=h3.device)
+    vers = {}                                              # one workspace per chunk length (at most two: 64 and the rest)
     for s in range(0, T, 64):                              # ASD_MAX_DRAFT_LEN positions per sequence per launch
         e = min(T, s + 64)
         zeros = torch.zeros((B, e - s), dtype=torch.float32, device=h3.device)
-        ver = K.LmHeadVerifier(lm_head_weight, B, e - s)
+        ver = vers.get(e - s)
+        if ver is None:
+            ver = vers[e - s] = K.LmHeadVerifier(lm_head_weight, B, e - s)
         r = ver(h3[:, s:e].contiguous(), tok[:, s:e].contiguous(), zeros, zeros + 1.0, inv_temperature=inv_temperature)
         out[:, s:e] = r.lp_target
     return out[0] if squeeze else out
