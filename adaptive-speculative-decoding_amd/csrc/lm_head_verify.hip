@@ -312,8 +312,15 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         }
         __syncthreads();
         if (*flag == 0u) return;
+        // every slice is added from its slab in slice order, the finisher's own included: the sum does not
+        // depend on which slice happened to arrive last (bit-reproducible results)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
         for (int sl = 0; sl < p.k_slices; ++sl) {
-            if (sl == slice) continue;
             const f32x4* in = slab(sl);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)

@@ -371,3 +371,45 @@ def test_lm_head_verify_non_finite_rows():
     keep[0, 1] = keep[1, 2] = False
     np.testing.assert_allclose(lp[keep], case["ref"]["lp_t64"][keep], rtol=0, atol=LMH_ATOL)
     assert r.n_acc[0].item() <= 1            # the NaN row ends sequence 0's accepted prefix
+
+
+def test_lm_head_verify_graph_replay_and_reproducibility():
+    """The fused call (incl. the sliced tail: a memset node + three kernels) captured in a hipGraph and replayed
+    on changing inputs equals the eager call bit for bit, and repeated eager calls are bit-identical (the
+    reduction slices are summed in slice order whatever their arrival order)."""
+    import torch
+
+    from asd_amd import kernels as Kn
+
+    B, K, D, V = 32, 8, 4608, 65700          # 256 wide blocks + one ragged 256-column block in 3 reduction slices
+    g = torch.Generator(device="cuda").manual_seed(9)
+    w = (torch.randn((V, D), device="cuda", generator=g) * (3.0 / D ** 0.5)).to(torch.bfloat16)
+    h = torch.randn((B * K, D), device="cuda", generator=g).to(torch.bfloat16)
+    tok = torch.randint(0, V, (B, K), device="cuda", generator=g, dtype=torch.int32)
+    lp_d = -torch.rand((B, K), device="cuda", generator=g)
+    u = torch.rand((B, K), device="cuda", generator=g)
+    ver = Kn.LmHeadVerifier(w, B, K)
+    first = ver(h, tok, lp_d, u)
+    ref_lp = first.lp_target.clone()
+    for _ in range(5):
+        again = ver(h, tok, lp_d, u)
+        assert torch.equal(again.lp_target, ref_lp)
+    out = ver(h, tok, lp_d, u)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ver(h, tok, lp_d, u, out=out)                      # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ver(h, tok, lp_d, u, out=out)
+    for seed in (1, 2, 3):
+        g2 = torch.Generator(device="cuda").manual_seed(seed)
+        h.copy_(torch.randn((B * K, D), device="cuda", generator=g2).to(torch.bfloat16))
+        u.copy_(torch.rand((B, K), device="cuda", generator=g2))
+        graph.replay()
+        torch.cuda.synchronize()
+        got_lp, got_acc = out.lp_target.clone(), out.accept.clone()
+        eager = ver(h, tok, lp_d, u)
+        torch.cuda.synchronize()
+        assert torch.equal(got_lp, eager.lp_target) and torch.equal(got_acc, eager.accept)
