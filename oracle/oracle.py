@@ -184,9 +184,12 @@ def lm_head_verify(hidden_bits: np.ndarray, weight_bits: np.ndarray, tok, lp_d, 
     inv_temperature is used exactly as the C oracle does.  Parity unpinned (A5 has no reference
     symbol).  Returns dict(lp_t64, accept, n_acc, bits, margin, logits64)."""
     h = bf16_bits_to_f32(np.asarray(hidden_bits)).astype(np.float64)
-    w = bf16_bits_to_f32(np.asarray(weight_bits)).astype(np.float64)
-    V = w.shape[0]
-    x = h @ w.T
+    wb = np.asarray(weight_bits)
+    V = wb.shape[0]
+    x = np.empty((h.shape[0], V), np.float64)
+    step = max(1, (1 << 27) // max(1, wb.shape[1]))     # <= 1 GiB of f64 weights at a time (a 152064 x 8192 head is 10 GB)
+    for v0 in range(0, V, step):
+        x[:, v0:v0 + step] = h @ bf16_bits_to_f32(wb[v0:v0 + step]).astype(np.float64).T
     a = float(np.float32(inv_temperature))
     lp, acc, n_acc = py_verify_accept((x * a).reshape(B, K, V), tok, lp_d, u)
     bits = np.array([sum(int(f) << k for k, f in enumerate(row)) for row in acc], dtype=np.uint64)

@@ -88,6 +88,11 @@ def check(got, ref):
     (32, 8, 128, 66000),     # wide (256-column) blocks for whole rounds of CUs + narrow blocks for the rest
     (32, 8, 4096, 65636),    # ... and, for a deep reduction, the rest as a 256-column block cut into 2 reduction
     (32, 8, 4608, 65700),    # slices / 3 slices (ticketed f32 slabs); the block is ragged (100 / 164 real columns)
+    (32, 8, 4608, 65536 + 3 * 256 - 56),   # THREE split-K tail tiles x 3 slices: slab index (nb*k_slices+sl)*8+wv and tickets[nb], nb > 0
+    (32, 8, 4096, 65536 + 5 * 256),        # five tail tiles x 2 slices, last tile full
+    (40, 8, 128, 4000),      # m_blocks = 2 with 32 narrow column blocks: the XCD-swizzled (mb, nb) map (n_blocks >= 8)
+    (40, 8, 128, 33000),     # m_blocks = 2 with 128 WIDE blocks (swizzled) + 2 narrow blocks in the plain order
+    (72, 8, 64, 3000),       # m_blocks = 3 (576 rows), 23 narrow blocks: 16 swizzled + 7 in the plain order
 ])
 def test_lm_head_verify_matches_oracle(B, K, D, V):
     case = make_case(B, K, D, V, seed=B * 1000 + K)
@@ -117,6 +122,70 @@ def test_lm_head_verify_deep_reduction_error_budget():
     err = np.abs(got["lp_t"].astype(np.float64) - case["ref"]["lp_t64"]).max()
     print(f"max |lp - oracle| at D=8192: {err:.3e}")
     check(got, case["ref"])
+
+
+def make_case_on_gpu(B, K, D, V, seed, scale=3.0):
+    """make_case for full-size heads: the operands are drawn on the GPU (1.2 G normals take numpy a minute) and
+    their bf16 bit patterns copied back for the f64 oracle, which sees exactly what the kernel reads."""
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    h = torch.randn((B * K, D), device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.empty((V, D), dtype=torch.bfloat16, device="cuda")
+    for v0 in range(0, V, 16384):
+        w[v0:v0 + 16384] = (torch.randn((min(16384, V - v0), D), device="cuda", generator=g) * (scale / D ** 0.5)).to(torch.bfloat16)
+    hb = h.view(torch.int16).cpu().numpy().view(np.uint16)
+    wb = w.view(torch.int16).cpu().numpy().view(np.uint16)
+    rng = np.random.default_rng(seed)
+    zeros, half = np.zeros((B, K), np.float32), np.full((B, K), 0.5, np.float32)
+    x = O.lm_head_verify(hb, wb, np.zeros((B, K), np.int32), zeros, half, B, K)["logits64"].reshape(B * K, V)
+    amax = x.argmax(axis=1)
+    tok = np.where(rng.uniform(size=B * K) < 0.7, amax, rng.integers(0, V, B * K)).astype(np.int32).reshape(B, K)
+    xs = x.reshape(B, K, V)
+    lp_t, _, _ = O.py_verify_accept(xs, tok, zeros, half)
+    lp_d = np.minimum(lp_t + rng.normal(0, 0.5, (B, K)), 0.0).astype(np.float32)
+    u = rng.uniform(0, 1, (B, K)).astype(np.float32)
+    for _ in range(100):
+        m = np.abs(np.log(u.astype(np.float64)) - (lp_t - lp_d.astype(np.float64)))
+        bad = ~(m >= LMH_MARGIN)
+        if not bad.any():
+            break
+        u[bad] = rng.uniform(0, 1, int(bad.sum())).astype(np.float32)
+    lp, acc, n_acc = O.py_verify_accept(xs, tok, lp_d, u)
+    bits = np.array([sum(int(f) << k for k, f in enumerate(row)) for row in acc], dtype=np.uint64)
+    ref = dict(lp_t64=lp, accept=acc, n_acc=n_acc, bits=bits)
+    return dict(B=B, K=K, D=D, V=V, h=h, w=w, tok=tok, lp_d=lp_d, u=u, ref=ref, argmax=amax.reshape(B, K))
+
+
+@pytest.mark.parametrize("name,D", [("72b", 8192), ("32b", 5120)])
+def test_lm_head_verify_real_heads_match_oracle_on_all_rows(name, D):
+    """The production shapes (BASELINE configs[2..4]): B = 32, K = 8, V = 152064 with the 72B (D = 8192) and
+    14B/32B (D = 5120) lm_head depths -- 512 wide blocks + 82 tail tiles x 3 reduction slices on 256 CUs --
+    against the f64 GEMM oracle on all 256 rows, arg-max included."""
+    import torch
+
+    from asd_amd import kernels as Kn
+
+    B, K, V = 32, 8, 152064
+    case = make_case_on_gpu(B, K, D, V, seed=D)
+    ver = Kn.LmHeadVerifier(case["w"], B, K)
+    am = torch.empty((B, K), dtype=torch.int32, device="cuda")
+    r = ver(case["h"], torch.from_numpy(case["tok"]).cuda(), torch.from_numpy(case["lp_d"]).cuda(),
+            torch.from_numpy(case["u"]).cuda(), argmax_out=am)
+    torch.cuda.synchronize()
+    got = dict(lp_t=r.lp_target.cpu().numpy(), accept=r.accept.cpu().numpy(), n_acc=r.n_acc.cpu().numpy(),
+               bits=r.accept_bits.cpu().numpy().view(np.uint64))
+    err = np.abs(got["lp_t"].astype(np.float64) - case["ref"]["lp_t64"]).max()
+    print(f"{name} head: max |lp - oracle| = {err:.3e}, n_acc = {got['n_acc'].tolist()}")
+    check(got, case["ref"])
+    # the arg-max may legitimately differ only where the two best f64 logits are closer than the f32 accumulation error
+    diff = am.cpu().numpy() != case["argmax"]
+    assert diff.sum() <= 1, f"{int(diff.sum())} arg-max rows differ"
+    # second call on the same workspace: tickets were re-zeroed by the launcher, results are bit-identical
+    r2 = ver(case["h"], torch.from_numpy(case["tok"]).cuda(), torch.from_numpy(case["lp_d"]).cuda(),
+             torch.from_numpy(case["u"]).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(r2.lp_target, r.lp_target) and torch.equal(r2.accept_bits, r.accept_bits)
 
 
 def test_lm_head_verify_agrees_with_materialised_logits_at_full_size():
