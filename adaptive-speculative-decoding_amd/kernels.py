@@ -440,8 +440,10 @@ class ResidualSampler:
 
     def __call__(self, t_logits: torch.Tensor, d_logits: torch.Tensor, n_acc: torch.Tensor, r: torch.Tensor,
                  bonus_logits: Optional[torch.Tensor] = None, inv_temperature: float = 1.0,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """t_logits / d_logits: [B,K,V]; bonus_logits: [B,V] or None; n_acc: [B] i32; r: [B] f32 -> token [B] i32."""
+                 out: Optional[torch.Tensor] = None, d_threshold: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """t_logits / d_logits: [B,K,V]; bonus_logits: [B,V] or None; n_acc: [B] i32; r: [B] f32 -> token [B] i32.
+        d_threshold: [B,K] f32 nucleus thresholds of the draft rows (DraftSampler's `thr`) when the drafts were
+        drawn with top-p (asd_residual_sample_ex); None = untruncated drafts."""
         Bv, K, V = t_logits.shape
         if d_logits.shape != t_logits.shape or d_logits.dtype != t_logits.dtype:
             raise ValueError("t_logits and d_logits must have the same shape and dtype")
@@ -450,8 +452,48 @@ class ResidualSampler:
         bp, ldb = (None, V) if bonus_logits is None else _rows(bonus_logits, "bonus_logits")
         if out is None:
             out = torch.empty((Bv,), dtype=torch.int32, device=t_logits.device)
-        rc = _lib().asd_residual_sample(tp, ldt, dp, ldd, bp, ldb, _DTYPE_CODE[t_logits.dtype],
-                                        _dev(n_acc, "n_acc", torch.int32), _dev(r, "r", torch.float32), Bv, K, V,
-                                        float(inv_temperature), out.data_ptr(), self.buf.data_ptr(), self.bytes, _stream())
-        B.check("asd_residual_sample", rc)
+        if d_threshold is not None and tuple(d_threshold.shape) != (Bv, K):
+            raise ValueError("d_threshold must be [B, K]")
+        rc = _lib().asd_residual_sample_ex(tp, ldt, dp, ldd, bp, ldb, _DTYPE_CODE[t_logits.dtype],
+                                           _dev(n_acc, "n_acc", torch.int32), _dev(r, "r", torch.float32), Bv, K, V,
+                                           float(inv_temperature), _opt(d_threshold, "d_threshold", torch.float32),
+                                           out.data_ptr(), self.buf.data_ptr(), self.bytes, _stream())
+        B.check("asd_residual_sample_ex", rc)
+        return out
+
+
+@dataclass
+class DraftDraw:
+    tok: torch.Tensor   # [B] i32  the proposed token
+    lp: torch.Tensor    # [B] f32  log q(tok) under the (nucleus-renormalised) draft distribution
+    thr: torch.Tensor   # [B] f32  nucleus threshold logit (-inf: no truncation)
+
+
+class DraftSampler:
+    """X1: asd_draft_sample with its workspace -- one call proposes the next token of every sequence from the
+    draft tier's next-token logits [B, V]: temperature and top-p folded in, inverse-CDF draw from caller-supplied
+    uniforms, log q(tok) for the verify step, nucleus threshold for the exact residual."""
+
+    def __init__(self, B_: int, V: int, dtype: torch.dtype = torch.bfloat16, device: Optional[torch.device] = None):
+        self.B, self.V, self.dtype = B_, V, dtype
+        self.bytes = int(_lib().asd_draft_sample_workspace_bytes(B_, V, _DTYPE_CODE[dtype]))
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device or torch.device("cuda"))
+
+    def __call__(self, logits: torch.Tensor, r: torch.Tensor, inv_temperature: float = 1.0, top_p: float = 1.0,
+                 out: Optional[DraftDraw] = None) -> DraftDraw:
+        if logits.dim() != 2 or logits.dtype != self.dtype or not logits.is_cuda or logits.stride(1) != 1:
+            raise ValueError(f"logits must be a [B, V] {self.dtype} CUDA tensor with unit stride along V")
+        Bv, V = logits.shape
+        if Bv > self.B or V != self.V:
+            raise ValueError(f"sampler was sized for B<={self.B}, V={self.V}")
+        dev = logits.device
+        if out is None:
+            out = DraftDraw(torch.empty((Bv,), dtype=torch.int32, device=dev),
+                            torch.empty((Bv,), dtype=torch.float32, device=dev),
+                            torch.empty((Bv,), dtype=torch.float32, device=dev))
+        rc = _lib().asd_draft_sample(logits.data_ptr(), logits.stride(0) if Bv > 1 else V, _DTYPE_CODE[logits.dtype],
+                                     _dev(r, "r", torch.float32), Bv, V, float(inv_temperature), float(top_p),
+                                     _dev(out.tok, "tok", torch.int32), _dev(out.lp, "lp", torch.float32),
+                                     _dev(out.thr, "thr", torch.float32), self.buf.data_ptr(), self.bytes, _stream())
+        B.check("asd_draft_sample", rc)
         return out

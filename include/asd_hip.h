@@ -283,6 +283,35 @@ int asd_residual_sample(const void* t_logits, int64_t ld_t, const void* d_logits
                         float inv_temperature, int32_t* token /*[B] out*/,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* asd_residual_sample for drafts that were drawn with nucleus (top-p) truncation (asd_draft_sample below): the draft
+ * distribution at row (b,k) is softmax(d_logits[b,k]/T) restricted to logits >= d_threshold[b,k] and renormalised --
+ * the distribution the drafted token was actually drawn from, so the residual max(0, p_t - p_d) stays exact.
+ * d_threshold: [B,K] f32 (asd_draft_sample's nucleus_logit per drafted position); NULL == asd_residual_sample. */
+int asd_residual_sample_ex(const void* t_logits, int64_t ld_t, const void* d_logits, int64_t ld_d,
+                           const void* bonus_logits, int64_t ld_b, int dtype,
+                           const int32_t* n_acc, const float* r, int B, int K, int V,
+                           float inv_temperature, const float* d_threshold /*[B,K] or NULL*/, int32_t* token,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * X1  the draft tier's per-step token proposal (north star piece (i)).  The reference delegates it to
+ * HF `model.generate(do_sample=True, temperature=0.7, top_p=0.9)` (src/training/generate_training_data.py:110-119;
+ * third-party arithmetic, parity unpinned); torch needs log_softmax + multinomial + gather over [B,V] per token.
+ * One call per drafted position, for row b (one next-token logits row per sequence):
+ *   q(v)   = softmax(logits[b]/T)(v) for v in the nucleus N_b, 0 outside, renormalised over N_b
+ *   N_b    = { v : logits[b,v] >= x*_b },  x*_b = the LARGEST logit value with  sum_{logits[b,v] >= x*} softmax(.)(v) >= top_p
+ *            (HF's TopPLogitsWarper set, with every token tied at the boundary value kept);  top_p outside (0,1): all v
+ *   tok[b] = min { v in N_b : sum_{v' in N_b, v' <= v} q(v') > r[b] }          (inverse CDF in vocabulary order, r in [0,1))
+ *   lp[b]  = log q(tok[b])                                       (the lp_draft the verify step needs; may be NULL)
+ *   nucleus_logit[b] = x*_b (-inf without truncation; may be NULL): with it asd_residual_sample_ex reconstructs q exactly.
+ * logits: [B rows][V] of `dtype`, rows ld ELEMENTS apart, 16-byte aligned, a whole number of 16-byte vectors.
+ * Rows must not contain NaN / +inf.  workspace: asd_draft_sample_workspace_bytes, 256-byte aligned, no initialisation.
+ * ---------------------------------------------------------------------------------------- */
+size_t asd_draft_sample_workspace_bytes(int B, int V, int dtype);
+int asd_draft_sample(const void* logits, int64_t ld, int dtype, const float* r /*[B]*/, int B, int V,
+                     float inv_temperature, float top_p, int32_t* tok /*[B] out*/, float* lp /*[B] out, may be NULL*/,
+                     float* nucleus_logit /*[B] out, may be NULL*/, void* workspace, size_t workspace_bytes, void* stream);
+
 /* N1, second form: asd_verify_accept with the epilogue of asd_predictor_stop run INSIDE the same
  * launch by the workgroup that completes each sequence (lp = the kernel's own lp_target, all K
  * positions valid).  One launch per tier step instead of two.  The in-kernel form covers the

@@ -130,22 +130,47 @@ def lse_partial(logits: np.ndarray, dtype: int, tok, B: int, K: int, V_shard: in
 
 
 def residual_sample(t_logits: np.ndarray, d_logits: np.ndarray, dtype: int, n_acc, r, B: int, K: int, V: int,
-                    bonus: Optional[np.ndarray] = None, inv_temperature: float = 1.0):
-    """asd_residual_sample in f64.  t_logits / d_logits: storage arrays [B*K, V]; bonus: [B, V] or None.
+                    bonus: Optional[np.ndarray] = None, inv_temperature: float = 1.0, d_threshold=None):
+    """asd_residual_sample in f64.  t_logits / d_logits: storage arrays [B*K, V]; bonus: [B, V] or None;
+    d_threshold: [B, K] f32 nucleus thresholds of the draft rows (asd_draft_sample) or None.
     Returns (token i32[B], margin f64[B])."""
     lib = _load()
     t_logits, d_logits = np.ascontiguousarray(t_logits), np.ascontiguousarray(d_logits)
     bonus = None if bonus is None else np.ascontiguousarray(bonus)
     n_acc = _c(n_acc, np.int32).reshape(-1)
     r = _c(r, np.float32).reshape(-1)
+    thr = None if d_threshold is None else _c(d_threshold, np.float32).reshape(-1)
     tok = np.empty(B, np.int32)
     margin = np.empty(B, np.float64)
     rc = lib.oracle_residual_sample(_p(t_logits), C.c_int64(V), _p(d_logits), C.c_int64(V), _p(bonus), C.c_int64(V),
                                     C.c_int(dtype), _p(n_acc), _p(r), C.c_int(B), C.c_int(K), C.c_int(V),
-                                    C.c_float(inv_temperature), _p(tok), _p(margin))
+                                    C.c_float(inv_temperature), _p(tok), _p(margin), _p(thr))
     if rc != 0:
         raise ValueError(rc)
     return tok, margin
+
+
+def draft_sample(logits: np.ndarray, dtype: int, r, B: int, V: int, inv_temperature: float = 1.0, top_p: float = 1.0,
+                 ld_row: Optional[int] = None):
+    """asd_draft_sample in f64 (X1; no reference arithmetic -- HF generate with temperature / top_p at
+    generate_training_data.py:110-119 -- so PARITY UNPINNED).  logits: storage array [B, ld_row].
+    Returns dict(tok i32[B], lp f64[B], thr f32[B] nucleus threshold logit (-inf = no truncation),
+    margin_p f64[B] (distance of top_p to the bracketing cumulative masses), margin_r f64[B] (CDF-edge distance))."""
+    lib = _load()
+    logits = np.ascontiguousarray(logits)
+    if ld_row is None:
+        ld_row = V
+    r = _c(r, np.float32).reshape(-1)
+    tok = np.empty(B, np.int32)
+    lp = np.empty(B, np.float64)
+    thr = np.empty(B, np.float32)
+    mp = np.empty(B, np.float64)
+    mr = np.empty(B, np.float64)
+    rc = lib.oracle_draft_sample(_p(logits), C.c_int64(ld_row), C.c_int(dtype), _p(r), C.c_int(B), C.c_int(V),
+                                 C.c_float(inv_temperature), C.c_float(top_p), _p(tok), _p(lp), _p(thr), _p(mp), _p(mr))
+    if rc != 0:
+        raise ValueError(rc)
+    return dict(tok=tok, lp=lp, thr=thr, margin_p=mp, margin_r=mr)
 
 
 def py_token_logprob_reference_idiom(score_row_f32: np.ndarray, token_id: int) -> float:

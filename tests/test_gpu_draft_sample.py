@@ -1,0 +1,157 @@
+"""asd_draft_sample (X1: the draft tier's per-step token proposal -- temperature, nucleus / top-p truncation,
+inverse-CDF draw, log q(tok)) and asd_residual_sample_ex (the residual against a nucleus-truncated draft row)
+against the f64 oracle.
+
+No reference arithmetic exists for this step: the reference calls HF `model.generate(do_sample=True,
+temperature=0.7, top_p=0.9)` (generate_training_data.py:110-119, third party) -> PARITY UNPINNED; what is pinned
+is the oracle's own definition (oracle/asd_oracle.c: nucleus_threshold, oracle_draft_sample).
+Bars: the nucleus threshold is bit-exact where top_p sits >= 1e-5 of mass away from the two cumulative masses that
+bracket it; the token is bit-exact where, additionally, the draw is >= 1e-5 of mass away from a CDF edge; lp within
+1e-5 (BASELINE: fp32 scores within 1e-5)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import encode_logits, to_device_logits
+
+pytestmark = pytest.mark.gpu
+
+LP_ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def K_():
+    from asd_amd import kernels
+    return kernels
+
+
+def _rows(B, V, dtype, seed, scale=3.0):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((B, V)) * scale).astype(np.float32)
+    return encode_logits(x, dtype), rng.uniform(0, 1, B).astype(np.float32)
+
+
+def _gpu(K_, store, r, B, V, dtype, inv_t, top_p):
+    import torch
+    lg = to_device_logits(store, dtype).view(B, V)
+    samp = K_.DraftSampler(B, V, lg.dtype)
+    d = samp(lg, torch.from_numpy(r).cuda(), inv_t, top_p)
+    torch.cuda.synchronize()
+    return d.tok.cpu().numpy(), d.lp.cpu().numpy(), d.thr.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32, O.DT_F16])
+@pytest.mark.parametrize("B,V,top_p,T", [
+    (32, 152064, 0.9, 0.7),     # the reference's sampling parameters on the Qwen vocabulary
+    (32, 152064, 1.0, 1.0),     # no truncation
+    (8, 1000, 0.9, 0.7),        # BASELINE configs[0] vocabulary
+    (5, 8, 0.5, 1.0),
+    (300, 4096, 0.95, 1.3),
+    (64, 32000, 0.3, 0.5),      # a tight nucleus (one to a few tokens)
+])
+def test_draft_sample_matches_oracle(K_, dtype, B, V, top_p, T):
+    store, r = _rows(B, V, dtype, seed=B * 7 + V)
+    inv_t = float(np.float32(1.0 / T))
+    ref = O.draft_sample(store, dtype, r, B, V, inv_t, top_p)
+    tok, lp, thr = _gpu(K_, store, r, B, V, dtype, inv_t, top_p)
+    ok_p = ref["margin_p"] > 1e-5
+    assert ok_p.mean() > 0.6
+    assert np.array_equal(thr[ok_p], ref["thr"][ok_p])                      # the nucleus itself
+    ok = ok_p & (ref["margin_r"] > 1e-5)
+    assert ok.mean() > 0.4
+    assert np.array_equal(tok[ok], ref["tok"][ok])
+    np.testing.assert_allclose(lp[ok], ref["lp"][ok], rtol=1e-6, atol=LP_ATOL)
+    # everywhere: the token is inside the nucleus the kernel reported, and lp <= 0
+    x = O.logits_as_f32(store, dtype)
+    assert (x[np.arange(B), tok] >= thr).all() and (lp <= 1e-6).all()
+    if not (0.0 < top_p < 1.0):
+        assert np.isneginf(thr).all()
+
+
+def test_draft_sample_strided_rows_ties_and_masked_logits(K_):
+    import torch
+    B, V = 6, 4096
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((B, V)) * 2).astype(np.float32)
+    x[0, :] = 1.5                      # a fully tied row: the nucleus is everything, the draw uniform
+    x[1, 100:] = -np.inf               # -inf logits (top-p / top-k masked rows) carry no mass
+    x[2, :] = np.round(x[2, :])        # many ties at the boundary value: all of them stay inside
+    x[3, 7] = 40.0                     # one token owns all the mass: nucleus of one
+    r = rng.uniform(0, 1, B).astype(np.float32)
+    r[4] = 0.0
+    store = encode_logits(x, O.DT_F32)
+    ref = O.draft_sample(store, O.DT_F32, r, B, V, 1.0, 0.9)
+    pad = torch.full((B, V + 64), 1.0e4, dtype=torch.float32, device="cuda")   # poisoned padding between rows
+    pad[:, :V] = torch.from_numpy(store).cuda()
+    samp = K_.DraftSampler(B, V, torch.float32)
+    d = samp(pad[:, :V], torch.from_numpy(r).cuda(), 1.0, 0.9)
+    torch.cuda.synchronize()
+    tok, lp, thr = d.tok.cpu().numpy(), d.lp.cpu().numpy(), d.thr.cpu().numpy()
+    ok = (ref["margin_p"] > 1e-5) & (ref["margin_r"] > 1e-5)
+    assert ok[[0, 1, 3]].all()
+    assert np.array_equal(thr[ref["margin_p"] > 1e-5], ref["thr"][ref["margin_p"] > 1e-5])
+    assert np.array_equal(tok[ok], ref["tok"][ok])
+    np.testing.assert_allclose(lp[ok], ref["lp"][ok], atol=LP_ATOL, rtol=1e-6)
+    assert thr[0] == 1.5 and abs(lp[0] - np.log(1.0 / V)) < 1e-5
+    assert tok[1] < 100 and tok[3] == 7 and abs(lp[3]) < 1e-6
+    # bitwise reproducible although the mass histogram is built with atomics (integer adds)
+    d2 = samp(pad[:, :V], torch.from_numpy(r).cuda(), 1.0, 0.9)
+    torch.cuda.synchronize()
+    assert torch.equal(d2.tok, d.tok) and torch.equal(d2.lp, d.lp) and torch.equal(d2.thr, d.thr)
+
+
+def test_draft_lp_feeds_the_verify_step_consistently(K_):
+    """log q(tok) from the draft sampler and log p(tok) from asd_verify_accept agree when both see the same row at
+    the same temperature without truncation (the acceptance ratio of a self-verified draft is 1)."""
+    import torch
+    B, V = 32, 152064
+    store, r = _rows(B, V, O.DT_BF16, seed=11)
+    lg = to_device_logits(store, O.DT_BF16).view(B, V)
+    inv_t = float(np.float32(1 / 0.7))
+    d = K_.DraftSampler(B, V, lg.dtype)(lg, torch.from_numpy(r).cuda(), inv_t, 1.0)
+    ws = K_.VerifyWorkspace(B, 1, V, lg.dtype)
+    v = K_.verify_accept(lg.view(B, 1, V), d.tok.view(B, 1), d.lp.view(B, 1).contiguous(),
+                         torch.full((B, 1), 0.999, device="cuda"), ws, inv_temperature=inv_t)
+    torch.cuda.synchronize()
+    assert (v.lp_target.view(-1) - d.lp).abs().max().item() < 2e-6
+    assert int(v.n_acc.sum()) >= B - 1
+
+
+@pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32])
+def test_residual_sample_against_a_nucleus_truncated_draft(K_, dtype):
+    """asd_residual_sample_ex: p_d is the top-p truncated, renormalised draft distribution (what the drafted token
+    was actually drawn from); thresholds come from asd_draft_sample on the same rows."""
+    import torch
+    B, K, V = 16, 4, 32000
+    rng = np.random.default_rng(5)
+    xt = (rng.standard_normal((B * K, V)) * 3).astype(np.float32)
+    xd = (xt + rng.standard_normal((B * K, V))).astype(np.float32)
+    st, sd = encode_logits(xt, dtype), encode_logits(xd, dtype)
+    sb = encode_logits((rng.standard_normal((B, V)) * 3).astype(np.float32), dtype)
+    n_acc = rng.integers(0, K + 1, B).astype(np.int32)
+    r = rng.uniform(0, 1, B).astype(np.float32)
+    inv_t = float(np.float32(1 / 0.7))
+    dref = O.draft_sample(sd, dtype, rng.uniform(0, 1, B * K).astype(np.float32), B * K, V, inv_t, 0.9)
+    thr = dref["thr"].reshape(B, K)
+    want, margin = O.residual_sample(st, sd, dtype, n_acc, r, B, K, V, bonus=sb, inv_temperature=inv_t, d_threshold=thr)
+    plain, _ = O.residual_sample(st, sd, dtype, n_acc, r, B, K, V, bonus=sb, inv_temperature=inv_t)
+    assert (want != plain).any(), "the truncation must matter in this case"
+    t = to_device_logits(st, dtype).view(B, K, V)
+    d = to_device_logits(sd, dtype).view(B, K, V)
+    bo = to_device_logits(sb, dtype).view(B, V)
+    got = K_.ResidualSampler(B, V, t.dtype)(t, d, torch.from_numpy(n_acc).cuda(), torch.from_numpy(r).cuda(), bo, inv_t,
+                                            d_threshold=torch.from_numpy(thr).cuda())
+    torch.cuda.synchronize()
+    ok = margin > 1e-5
+    assert ok.mean() > 0.5
+    assert np.array_equal(got.cpu().numpy()[ok], want[ok])
+
+
+def test_draft_sample_status_codes(K_):
+    import torch
+    samp = K_.DraftSampler(2, 1001, torch.bfloat16)
+    with pytest.raises(K_.B.AsdError):          # rows are not whole 16-byte vectors
+        samp(torch.zeros((2, 1001), dtype=torch.bfloat16, device="cuda"), torch.zeros(2, device="cuda"))
+    with pytest.raises(ValueError):
+        K_.DraftSampler(2, 1000, torch.bfloat16)(torch.zeros((2, 1000), dtype=torch.float32, device="cuda"),
+                                                  torch.zeros(2, device="cuda"))
