@@ -61,13 +61,58 @@ class HipOps:
         r = self.K.accept_from_partials(msg_all, lp_d, u, inv_temperature=inv_temperature)
         return r.lp_target, r.accept, r.n_acc, r.accept_bits
 
-    def lm_head_partial(self, hidden, weight_shard, tok, v_offset, inv_temperature: float = 1.0):
-        B, K = tok.shape
-        key = ("lmh", weight_shard.data_ptr(), B, K)
+    def _lm_head(self, weight, B, K):
+        key = ("lmh", weight.data_ptr(), B, K)
         ver = self._ws.get(key)
         if ver is None:
-            ver = self._ws[key] = self.K.LmHeadVerifier(weight_shard, B, K)
-        return ver.partial(hidden, tok, v_offset, inv_temperature)
+            ver = self._ws[key] = self.K.LmHeadVerifier(weight, B, K)
+        return ver
+
+    def lm_head_partial(self, hidden, weight_shard, tok, v_offset, inv_temperature: float = 1.0):
+        B, K = tok.shape
+        return self._lm_head(weight_shard, B, K).partial(hidden, tok, v_offset, inv_temperature)
+
+    def lm_head_verify(self, hidden, weight, tok, lp_d, u, inv_temperature: float = 1.0):
+        """N2: verify from hidden states [n,K,D] and the [V,D] lm_head matrix (logits stay in MFMA accumulators)."""
+        B, K = tok.shape
+        r = self._lm_head(weight, B, K)(hidden, tok, lp_d, u, inv_temperature=inv_temperature)
+        return r.lp_target, r.accept, r.n_acc, r.accept_bits
+
+    # -- the rest of a tier step (serving/hierarchy.py): stop decision, proposal, commit draw, bookkeeping
+    def pack_predictor(self, predictor, device):
+        """predictor: MinimalQualityPredictor-like (weights_numpy / input_dim / hidden_dim) -> opaque handle."""
+        return (self.K.pack_mlp_weights(*predictor.weights_numpy(), device=device), predictor.input_dim, predictor.hidden_dim)
+
+    def predictor_stop(self, pred, lp, feat, p_hist, stage_idx, costs, lam, risk_adjustment=True, n_obs=100, alpha=1.0,
+                       beta=1.0, stats_col=5):
+        """asd_predictor_stop on [n] sequences: p_hist [n,L] f64 is updated in place (column stage_idx) and returned
+        with (score f32 [n], k_star i32 [n])."""
+        packed, in_dim, hidden = pred
+        r = self.K.predictor_stop(feat, packed, in_dim, hidden, stage_idx=stage_idx, L=p_hist.shape[1], lp=lp,
+                                  stats_col=stats_col, risk_adjustment=risk_adjustment, n_obs=n_obs, alpha=alpha, beta=beta,
+                                  p_hist=p_hist, Cc=costs, lam=lam)
+        return r.score, r.k_star, p_hist
+
+    def _sampler(self, kind, B, V, dtype, device):
+        key = (kind, V, str(dtype), str(device))
+        s = self._ws.get(key)
+        if s is None or s.B < B:
+            cls = self.K.DraftSampler if kind == "draft" else self.K.ResidualSampler
+            s = self._ws[key] = cls(B, V, dtype, device)
+        return s
+
+    def draft_sample(self, logits, r, inv_temperature: float = 1.0, top_p: float = 1.0):
+        """X1: logits [B,V] -> (tok i32 [B], log q(tok) f32 [B], nucleus threshold f32 [B])."""
+        d = self._sampler("draft", logits.shape[0], logits.shape[1], logits.dtype, logits.device)(logits, r, inv_temperature, top_p)
+        return d.tok, d.lp, d.thr
+
+    def residual_sample(self, t_logits, d_logits, n_acc, r, bonus, inv_temperature: float = 1.0, d_threshold=None):
+        """t_logits / d_logits [n,K,V], bonus [n,V], n_acc i32 [n], r f32 [n] -> committed token i32 [n]."""
+        s = self._sampler("residual", t_logits.shape[0], t_logits.shape[2], t_logits.dtype, t_logits.device)
+        return s(t_logits, d_logits, n_acc, r, bonus, inv_temperature, d_threshold=d_threshold)
+
+    def commit_step(self, tok, n_acc, drawn, seq_len, tokens, n_commit, max_len):
+        self.K.commit_step(tok, n_acc, drawn, seq_len, tokens, n_commit, max_len=max_len)
 
 
 def _world(group) -> Tuple[int, int]:

@@ -1,0 +1,647 @@
+"""Three-tier token-level loop with the optimal-stopping rule LIVE: draft -> verify -> stop-or-escalate
+(BASELINE configs[3] / [4]; the reference's stop-or-continue loop is src/serving/pipeline.py:248-266).
+
+The reference runs its stages as a cascade of whole answers: stage i generates, the quality predictor turns the
+stage's log-probs into an acceptance probability p_i, `bayesian_adjustment` shrinks it, `optimal_stopping_rule`
+decides whether stage i's output is final (pipeline.py:225-261).  Here the same decision runs per drafted BLOCK:
+
+  tier 0   (7B)   drafts K tokens per sequence (asd_draft_sample: temperature + top-p, log q(tok)); its "output"
+                  is the block itself, judged from its own log-probs lp_d  ->  p_0
+  tier s>=1       verifies the SAME block for the sequences still active (asd_verify_accept / asd_lm_head_verify):
+                  lp_t^(s), accept mask, n_acc^(s); judged from lp_t^(s)  ->  p_s
+  stop rule       asd_predictor_stop(stage_idx = s, p_hist carried): p_s = bayes(predictor(stats(lp))),
+                  k* = optimal_stopping_rule(p_hist[b, :], C, lambda) over ALL L tiers (tiers not run yet keep the
+                  prior 1.0, the last tier is forced);  sequence b STOPS at tier s iff k* <= s, else it ESCALATES:
+                  tier s+1 re-verifies the same drafted tokens (its own uniforms), after catching its KV cache up
+                  on the tokens committed while it was idle.
+  commit          the verdict of the tier a sequence stopped at is final: n_acc accepted tokens + one token drawn by
+                  that tier from the residual max(0, p_t - p_d) at the first rejection (p_d = the nucleus-truncated
+                  draft distribution) or from its bonus row; asd_commit_step appends per sequence (ragged).
+  min_verify_stage = 1 (default): a block is verified at least once (k* = 0 is read as "continue"), so the output
+                  is always distributed as SOME verifying tier's distribution.  0 = the reference's pure cascade:
+                  a sequence whose k* is 0 commits its K drafted tokens unverified.
+
+Everything above is arithmetic behind `ops` (distributed.HipOps -> libasd_hip.so; the CPU test-suite injects the
+oracle, tests/oracle_backend.py).  Model execution (SyntheticLM, per-sequence KV) and message passing are torch
+plumbing.  One code path serves every placement: a `Placement` maps the roles "draft", "t1", "t2", ... to ranks;
+roles on the same rank hand tensors over directly, roles on different ranks use point-to-point send / recv
+(RCCL over xGMI on the GPU box, gloo in the CPU tests) of the SMALL messages only:
+
+  draft -> tier s     tok [B,K] i32, lp_d [B,K] f32, p_0 [B] f64, stop_0 [B]            (2.3 KB at B=32, K=8)
+  tier s -> tier s+1  escalate [B] u8 + p_hist[:, :s+1] f64                              (< 1 KB)
+  tier s -> draft     active / stop / n_acc [B] i32                                      (384 B)
+  draft -> tier s     ONE draft-logits row (storage dtype) + its nucleus threshold per sequence that stopped at
+                      tier s WITH a rejection (all-accepted sequences draw from the tier's own bonus row)
+  tier s -> draft     drawn [B] i32;   draft -> all: final n_acc / drawn / tier [B] i32
+
+The [B,K,V] target logits never leave the rank that produced them.  A tier whose lm_head is vocab-sharded over a
+group of ranks (72B over 2 / 4 GPUs) reduces each shard to (m2, s, g) triples (asd_lm_head_partial), all-gathers
+[n,K,3] floats, and all-gathers the shard pieces of the one row per stopping sequence its draw needs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..distributed import HipOps, shard_bounds
+
+
+@dataclass
+class HierarchyConfig:
+    draft_len: int = 8
+    temperature: float = 0.7                 # generate_training_data.py:110-119, pipeline.py:94
+    top_p: float = 0.9                       # nucleus of the DRAFT tier (>= 1: off)
+    stage_costs: Sequence[float] = (1.0, 4.5, 10.0)   # BASELINE.md cost units 7B / 32B / 72B
+    lambda_value: float = 1.0
+    risk_adjustment: bool = True             # pipeline.py:234-238
+    risk_alpha: float = 1.0
+    risk_beta: float = 1.0
+    n_obs: int = 100
+    stats_col: int = 5                       # extract_features columns [5:10] (generate_training_data.py:166-175)
+    min_verify_stage: int = 1
+    seed: int = 0
+
+
+def prompt_features(prompt_ids: torch.Tensor) -> torch.Tensor:
+    """A9 (minimal_adaptive_decoder.py:51-68) from token ids: [len/512, distinct/len, words/100, 0 x 61] per sequence;
+    with ids only, a "word" is a token.  float32 [B, 64] on the prompt's device."""
+    from ..minimal_adaptive_decoder import features_from_token_ids
+    rows = [features_from_token_ids(r, " ".join("t" for _ in r)) for r in prompt_ids.cpu().tolist()]
+    return torch.from_numpy(np.stack(rows)).to(prompt_ids.device)
+
+
+# ------------------------------------------------------------------------------------------- messages
+@dataclass
+class DraftMsg:
+    tok: torch.Tensor      # [B,K] i32
+    lp_d: torch.Tensor     # [B,K] f32
+    p0: torch.Tensor       # [B] f64   stage-0 adjusted probability
+    stop0: torch.Tensor    # [B] u8    1: the block is committed unverified (min_verify_stage == 0 only)
+
+
+@dataclass
+class EscMsg:
+    escalate: torch.Tensor  # [B] u8
+    p_prev: torch.Tensor    # [B, s+1] f64: p_hist columns 0..s of the tiers that already judged the block
+
+
+@dataclass
+class Verdict:
+    active: torch.Tensor   # [B] i32  1: this tier verified the sequence this step
+    stop: torch.Tensor     # [B] i32  1: ... and its verdict is final
+    n_acc: torch.Tensor    # [B] i32  accepted prefix (valid where active)
+    # trace only (never cross a link)
+    idx: Optional[torch.Tensor] = None
+    accept: Optional[torch.Tensor] = None
+    k_star: Optional[torch.Tensor] = None
+    score: Optional[torch.Tensor] = None
+    p_hist: Optional[torch.Tensor] = None
+    inputs: Optional[dict] = None
+
+
+@dataclass
+class FinalMsg:
+    n_acc: torch.Tensor    # [B] i32
+    drawn: torch.Tensor    # [B] i32
+    tier: torch.Tensor     # [B] i32  the tier whose verdict was committed
+
+
+def _dev_gen(device, seed: int) -> torch.Generator:
+    return torch.Generator(device=device).manual_seed(int(seed))
+
+
+class _SeqState:
+    """The per-role replica of the committed token buffer (every role commits the same FinalMsg)."""
+
+    def __init__(self, prompt_ids: torch.Tensor, max_new_tokens: int, K: int):
+        dev = prompt_ids.device
+        self.B, self.P = prompt_ids.shape
+        if self.P < 2:
+            raise ValueError("the loop needs a prompt of at least two tokens")
+        self.K = K
+        self.cap = self.P + max_new_tokens
+        self.kv_slots = self.cap + K + 3                     # + the trash slot forward_ragged clamps padding into
+        self.tokens = torch.zeros((self.B, self.cap), dtype=torch.int32, device=dev)
+        self.tokens[:, :self.P] = prompt_ids.to(torch.int32)
+        self.seq_len = torch.full((self.B,), self.P, dtype=torch.int32, device=dev)
+        self.n_commit = torch.zeros((self.B,), dtype=torch.int32, device=dev)
+        self.steps = 0
+
+    def window(self) -> int:
+        """Host-side bound on every position a step can touch (no device read-back)."""
+        return min(self.P + self.steps * (self.K + 1) + self.K + 2, self.kv_slots)
+
+    def commit(self, ops, tok: torch.Tensor, final: FinalMsg) -> None:
+        ops.commit_step(tok, final.n_acc, final.drawn, self.seq_len, self.tokens, self.n_commit, self.cap)
+        self.steps += 1
+
+
+# ------------------------------------------------------------------------------------------- tier 0
+class DraftRole:
+    def __init__(self, model, cfg: HierarchyConfig, ops, prompt_ids: torch.Tensor, max_new_tokens: int, predictor,
+                 feat: Optional[torch.Tensor] = None):
+        self.m, self.cfg, self.ops = model, cfg, ops
+        self.st = _SeqState(prompt_ids, max_new_tokens, cfg.draft_len)
+        dev = prompt_ids.device
+        B, K = self.st.B, cfg.draft_len
+        self.gen = _dev_gen(dev, cfg.seed)
+        self.inv_t = float(np.float32(1.0 / cfg.temperature))
+        self.L = len(cfg.stage_costs)
+        self.costs = torch.tensor(list(cfg.stage_costs), dtype=torch.float64, device=dev)
+        self.pred = ops.pack_predictor(predictor, dev)
+        self.feat = prompt_features(prompt_ids) if feat is None else feat
+        model.reset()
+        model.alloc_ragged(B, self.st.kv_slots)
+        if self.st.P > 2:
+            model.forward_ragged(prompt_ids[:, :self.st.P - 2], torch.zeros((B,), dtype=torch.int64, device=dev), self.st.P)
+        self.rows_b = torch.arange(B, device=dev)
+        self.d_logits: Optional[torch.Tensor] = None       # [B,K,V] of the current block (storage dtype)
+        self.thr = torch.empty((B, K), dtype=torch.float32, device=dev)
+        self.tok = torch.empty((B, K), dtype=torch.int32, device=dev)
+        self.lp_d = torch.empty((B, K), dtype=torch.float32, device=dev)
+
+    @torch.no_grad()
+    def propose(self) -> DraftMsg:
+        st, cfg, K = self.st, self.cfg, self.cfg.draft_len
+        B = st.B
+        L = st.seq_len.to(torch.int64)
+        w = st.window()
+        last2 = torch.stack([st.tokens[self.rows_b, L - 2], st.tokens[self.rows_b, L - 1]], 1).to(torch.int64)
+        dl = self.m.forward_ragged(last2, L - 2, w)[:, -1]
+        if self.d_logits is None:
+            self.d_logits = torch.empty((B, K, dl.shape[-1]), dtype=dl.dtype, device=dl.device)
+        for k in range(K):
+            self.d_logits[:, k] = dl
+            r = torch.rand((B,), generator=self.gen, device=dl.device)
+            t, lp, thr = self.ops.draft_sample(self.d_logits[:, k], r, self.inv_t, cfg.top_p)
+            self.tok[:, k], self.lp_d[:, k], self.thr[:, k] = t, lp, thr
+            if k + 1 < K:
+                dl = self.m.forward_ragged(t[:, None].to(torch.int64), L + k, w)[:, -1]
+        # stage 0 of the stop rule: the draft tier judged from its own log-probs
+        ph = torch.ones((B, self.L), dtype=torch.float64, device=dl.device)
+        _, k0, ph = self.ops.predictor_stop(self.pred, self.lp_d, self.feat, ph, 0, self.costs, cfg.lambda_value,
+                                            cfg.risk_adjustment, cfg.n_obs, cfg.risk_alpha, cfg.risk_beta, cfg.stats_col)
+        stop0 = (k0 <= 0).to(torch.uint8) if cfg.min_verify_stage <= 0 else torch.zeros((B,), dtype=torch.uint8, device=dl.device)
+        if self.L == 1:
+            stop0.fill_(1)
+        return DraftMsg(self.tok.clone(), self.lp_d.clone(), ph[:, 0].contiguous(), stop0)
+
+    def rows_for(self, v: Verdict) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """The draft-logits rows tier s needs for its residual draws: one per sequence that stopped there with a
+        rejection, ascending in b.  Returns (b indices, rows [n,V], thresholds [n])."""
+        need = (v.stop == 1) & (v.n_acc < self.cfg.draft_len)
+        b = need.nonzero()[:, 0]
+        j = v.n_acc.to(torch.int64)[b]
+        return b, self.d_logits[b, j].contiguous(), self.thr[b, j].contiguous()
+
+    def assemble(self, dm: DraftMsg, verdicts: List[Tuple[int, Verdict, torch.Tensor]]) -> FinalMsg:
+        """verdicts: (stage_idx, Verdict, drawn [B]) of every tier that ran this step."""
+        K = self.cfg.draft_len
+        n_acc = torch.full_like(self.st.seq_len, K - 1)
+        drawn = dm.tok[:, K - 1].clone()
+        tier = torch.zeros_like(self.st.seq_len)
+        for s, v, d in verdicts:
+            m = v.stop == 1
+            n_acc = torch.where(m, v.n_acc, n_acc)
+            drawn = torch.where(m, d, drawn)
+            tier = torch.where(m, torch.full_like(tier, s), tier)
+        return FinalMsg(n_acc.contiguous(), drawn.contiguous(), tier.contiguous())
+
+    def commit(self, dm: DraftMsg, final: FinalMsg) -> None:
+        self.st.commit(self.ops, dm.tok, final)
+
+
+# ------------------------------------------------------------------------------------------- heads
+class LogitsHead:
+    """Materialised logits: lm_head GEMM (rocBLAS) -> asd_verify_accept on the [n,K,V] tensor."""
+
+    def __init__(self, model, ops):
+        self.m, self.ops = model, ops
+        self._logits = None
+
+    def score(self, hid, tok, lp_d, u, inv_t):
+        self._logits = self.m.lm_head(hid) * self.m.logit_scale          # [n, K+1, V], row K = bonus row
+        K = tok.shape[1]
+        return self.ops.verify_accept(self._logits[:, :K].contiguous(), tok, lp_d, u, inv_temperature=inv_t)
+
+    def draw_rows(self, sel: torch.Tensor, j: torch.Tensor) -> torch.Tensor:
+        """Target logits row j[i] of local sequence sel[i] -> [m, V]."""
+        return self._logits[sel, j].contiguous()
+
+
+class FusedHead:
+    """N2: asd_lm_head_verify on the hidden states (no [n,K,V] logits); the one row per sequence a draw needs
+    is a skinny GEMM."""
+
+    def __init__(self, model, ops):
+        self.m, self.ops = model, ops
+        self._hid = None
+
+    def score(self, hid, tok, lp_d, u, inv_t):
+        self._hid = hid
+        K = tok.shape[1]
+        return self.ops.lm_head_verify(hid[:, :K].contiguous(), self.m.lm_head.weight, tok, lp_d, u,
+                                       inv_temperature=float(np.float32(inv_t * self.m.logit_scale)))
+
+    def draw_rows(self, sel, j):
+        return (self.m.lm_head(self._hid[sel, j]) * self.m.logit_scale).contiguous()
+
+
+class ShardedHead:
+    """The tier's lm_head split along the vocabulary over `group` (72B over 2 / 4 ranks): every rank holds rows
+    [v0, v1) of the matrix (`model.lm_head.weight` is the SHARD), reduces them to (m2, s, g) triples without forming
+    logits (asd_lm_head_partial), and the group all-gathers [n,K,3] floats.  Draw rows are all-gathered shard pieces."""
+
+    def __init__(self, model, ops, vocab: int, group=None):
+        from ..distributed import VocabShardedVerifier
+        self.m, self.ops, self.group = model, ops, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.v0, self.v1 = shard_bounds(vocab, self.world, self.rank)
+        self.vocab = vocab
+        self.ver = VocabShardedVerifier(vocab, ops=ops, group=group)
+        self._hid = None
+        self.bytes_exchanged = 0
+
+    def score(self, hid, tok, lp_d, u, inv_t):
+        self._hid = hid
+        K = tok.shape[1]
+        self.ver.inv_temperature = float(np.float32(inv_t * self.m.logit_scale))
+        self.bytes_exchanged += tok.shape[0] * K * 12 * (self.world - 1)
+        return self.ver.verify_hidden(hid[:, :K].contiguous(), self.m.lm_head.weight, tok, lp_d, u)
+
+    def draw_rows(self, sel, j):
+        piece = (self.m.lm_head(self._hid[sel, j]) * self.m.logit_scale).contiguous()     # [m, v1-v0]
+        width = max(shard_bounds(self.vocab, self.world, r)[1] - shard_bounds(self.vocab, self.world, r)[0]
+                    for r in range(self.world))
+        pad = torch.zeros((piece.shape[0], width), dtype=piece.dtype, device=piece.device)
+        pad[:, :piece.shape[1]] = piece
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        self.bytes_exchanged += pad.numel() * pad.element_size() * (self.world - 1)
+        cols = [p[:, :shard_bounds(self.vocab, self.world, r)[1] - shard_bounds(self.vocab, self.world, r)[0]]
+                for r, p in enumerate(parts)]
+        return torch.cat(cols, 1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------- tiers s >= 1
+class VerifyRole:
+    def __init__(self, model, stage_idx: int, cfg: HierarchyConfig, ops, prompt_ids: torch.Tensor, max_new_tokens: int,
+                 predictor, head=None, feat: Optional[torch.Tensor] = None, keep_inputs: bool = False):
+        self.m, self.s, self.cfg, self.ops = model, stage_idx, cfg, ops
+        self.st = _SeqState(prompt_ids, max_new_tokens, cfg.draft_len)
+        dev = prompt_ids.device
+        B = self.st.B
+        self.gen = _dev_gen(dev, cfg.seed + 7919 * stage_idx)
+        self.inv_t = float(np.float32(1.0 / cfg.temperature))
+        self.L = len(cfg.stage_costs)
+        self.last = stage_idx == self.L - 1
+        self.costs = torch.tensor(list(cfg.stage_costs), dtype=torch.float64, device=dev)
+        self.pred = ops.pack_predictor(predictor, dev)
+        self.feat = prompt_features(prompt_ids) if feat is None else feat
+        self.head = head if head is not None else LogitsHead(model, ops)
+        self.keep_inputs = keep_inputs
+        model.reset()
+        model.alloc_ragged(B, self.st.kv_slots)
+        model.forward_ragged(prompt_ids[:, :self.st.P - 1], torch.zeros((B,), dtype=torch.int64, device=dev), self.st.P)
+        self.kv_len = torch.full((B,), self.st.P - 1, dtype=torch.int64, device=dev)   # KV valid for positions < kv_len
+        self._fed: Optional[torch.Tensor] = None            # sequences fed this step (their KV advanced)
+        self._pending = None
+        self.fed_tokens = 0                                 # model positions computed (cost accounting)
+
+    def _empty(self) -> Verdict:
+        z = torch.zeros_like(self.st.seq_len)
+        return Verdict(z, z.clone(), z.clone())
+
+    @torch.no_grad()
+    def verify(self, dm: DraftMsg, esc: Optional[EscMsg]) -> Tuple[Verdict, EscMsg]:
+        st, cfg, K = self.st, self.cfg, self.cfg.draft_len
+        B, dev = st.B, st.tokens.device
+        self._pending = None
+        self._fed = None
+        if esc is None:                                     # tier 1 sees every block that was not committed at stage 0
+            act = dm.stop0 == 0
+            p_prev = dm.p0[:, None]
+        else:
+            act = esc.escalate == 1
+            p_prev = esc.p_prev
+        idx = act.nonzero()[:, 0]                           # host sync: the size of this tier's sub-batch
+        n = idx.numel()
+        out_esc = EscMsg(torch.zeros((B,), dtype=torch.uint8, device=dev),
+                         torch.ones((B, self.s + 1), dtype=torch.float64, device=dev))
+        if n == 0:
+            return self._empty(), out_esc
+        L = st.seq_len.to(torch.int64)[idx]
+        kv = self.kv_len[idx]
+        lag = L - 1 - kv                                    # committed tokens this tier has not seen yet
+        every_step = self.s == 1 and cfg.min_verify_stage >= 1           # tier 1 then sees every block: lag == 0
+        T = K + 1 if every_step else int(lag.max().item()) + K + 1
+        pos = kv[:, None] + torch.arange(T, device=dev)
+        committed = st.tokens[idx].gather(1, pos.clamp(max=st.cap - 1)).to(torch.int64)
+        tok_i = dm.tok[idx]
+        drafted = tok_i.gather(1, (pos - L[:, None]).clamp(0, K - 1)).to(torch.int64)
+        ids = torch.where(pos < L[:, None], committed, torch.where(pos < (L + K)[:, None], drafted, torch.zeros_like(drafted)))
+        hid = self.m.forward_ragged(ids, kv, st.window(), return_hidden=True, rows=None if n == B else idx)
+        self.fed_tokens += n * T
+        sel = lag[:, None] + torch.arange(K + 1, device=dev)
+        hid = hid.gather(1, sel[:, :, None].expand(-1, -1, hid.shape[-1]))              # [n, K+1, D]
+        u = torch.rand((B, K), generator=self.gen, device=dev)[idx].contiguous()
+        self._r = torch.rand((B,), generator=self.gen, device=dev)
+        lp_d = dm.lp_d[idx].contiguous()
+        tok_i = tok_i.contiguous()
+        lp_t, accept, n_acc, bits = self.head.score(hid, tok_i, lp_d, u, self.inv_t)
+        # stop rule: p_hist columns < s from the tiers below, column s from this tier's log-probs, priors 1.0 above
+        ph = torch.ones((n, self.L), dtype=torch.float64, device=dev)
+        ph[:, :self.s] = p_prev[idx, :self.s]
+        score, k_star, ph = self.ops.predictor_stop(self.pred, lp_t.contiguous(), self.feat[idx].contiguous(), ph, self.s,
+                                                    self.costs, cfg.lambda_value, cfg.risk_adjustment, cfg.n_obs,
+                                                    cfg.risk_alpha, cfg.risk_beta, cfg.stats_col)
+        stop = torch.ones((n,), dtype=torch.bool, device=dev) if self.last else (k_star <= self.s)
+        z = torch.zeros((B,), dtype=torch.int32, device=dev)
+        v = Verdict(z.index_put((idx,), torch.ones((n,), dtype=torch.int32, device=dev)),
+                    z.index_put((idx,), stop.to(torch.int32)), z.index_put((idx,), n_acc.to(torch.int32)),
+                    idx=idx, accept=accept, k_star=k_star, score=score, p_hist=ph)
+        if self.keep_inputs:
+            v.inputs = dict(tok=tok_i.clone(), lp_d=lp_d.clone(), u=u.clone(), lp_t=lp_t.clone(), n_acc=n_acc.clone(),
+                            hidden=hid[:, :K].clone(), feat=self.feat[idx].clone())
+            if isinstance(self.head, LogitsHead):
+                v.inputs["logits"] = self.head._logits[:, :K].clone()
+        out_esc.escalate[idx] = (~stop).to(torch.uint8)
+        out_esc.p_prev[idx] = ph[:, :self.s + 1]
+        self._fed = idx
+        self._pending = (idx, stop, n_acc)
+        return v, out_esc
+
+    def rows_expected(self, v: Verdict) -> torch.Tensor:
+        """b indices (ascending) whose draft row the draft rank will send: stopped here with a rejection."""
+        return ((v.stop == 1) & (v.n_acc < self.cfg.draft_len)).nonzero()[:, 0]
+
+    @torch.no_grad()
+    def draw(self, b_rows: torch.Tensor, d_rows: torch.Tensor, d_thr: torch.Tensor) -> torch.Tensor:
+        """The token every sequence that STOPPED at this tier commits after its accepted prefix -> drawn [B] i32
+        (0 elsewhere).  b_rows / d_rows / d_thr: DraftRole.rows_for of this tier's verdict."""
+        B, dev, K = self.st.B, self.st.tokens.device, self.cfg.draft_len
+        drawn = torch.zeros((B,), dtype=torch.int32, device=dev)
+        if self._pending is None:
+            return drawn
+        idx, stop, n_acc = self._pending
+        sel = stop.nonzero()[:, 0]                          # local positions of the stopping sequences
+        m = sel.numel()
+        if m == 0:
+            return drawn
+        b_sel = idx[sel]
+        j = n_acc.to(torch.int64)[sel]
+        t_rows = self.head.draw_rows(sel, j)                # [m, V]: row n_acc (the bonus row when n_acc == K)
+        d_full = torch.zeros_like(t_rows)
+        thr = torch.full((m,), float("-inf"), dtype=torch.float32, device=dev)
+        if b_rows.numel():
+            where = torch.searchsorted(b_sel, b_rows)       # b_sel ascending (idx and sel are)
+            d_full[where] = d_rows.to(t_rows.dtype)
+            thr[where] = d_thr
+        all_acc = (j >= K).to(torch.int32)                  # K = 1 view: 0 -> residual of the two rows, 1 -> bonus draw
+        tokd = self.ops.residual_sample(t_rows[:, None, :], d_full[:, None, :], all_acc.contiguous(), self._r[b_sel].contiguous(),
+                                        t_rows, self.inv_t, d_threshold=thr[:, None].contiguous())
+        drawn[b_sel] = tokd.to(torch.int32)
+        return drawn
+
+    def commit(self, dm: DraftMsg, final: FinalMsg) -> None:
+        cand = None
+        if self._fed is not None:                           # fed positions L .. L+K-1 hold the drafted tokens' KV
+            cand = self.st.seq_len.to(torch.int64)[self._fed] + final.n_acc.to(torch.int64)[self._fed]
+        self.st.commit(self.ops, dm.tok, final)
+        if cand is not None:                                # ... of which the accepted prefix stays valid (the commit may
+            new_len = self.st.seq_len.to(torch.int64)[self._fed]            # have been cut short at the buffer's end)
+            self.kv_len[self._fed] = torch.minimum(cand, new_len - 1)
+        self._fed = self._pending = None                    # a step in which this tier is not called feeds nothing
+
+
+# ------------------------------------------------------------------------------------------- drivers
+@dataclass
+class HierarchyTrace:
+    tokens: torch.Tensor                    # [B, P + max_new] int32 (prompt + committed)
+    seq_len: torch.Tensor
+    steps: int = 0
+    verified_tokens: int = 0                # tokens appended, all sequences, all steps
+    tier_counts: List[int] = field(default_factory=list)     # sequences-steps whose verdict came from tier s
+    tier_calls: List[int] = field(default_factory=list)      # sequence-steps each tier verified
+    fed_tokens: List[int] = field(default_factory=list)      # model positions each verify tier computed
+    records: List[dict] = field(default_factory=list)        # per step (keep_inputs)
+    bytes_sent: Dict[str, int] = field(default_factory=dict)
+    rows_shipped: int = 0
+
+    @property
+    def stop_rate(self) -> List[float]:
+        tot = max(1, sum(self.tier_counts))
+        return [c / tot for c in self.tier_counts]
+
+
+def _account(tr: HierarchyTrace, L: int, final: FinalMsg, verdicts) -> None:
+    t = final.tier.cpu().numpy()
+    for s in range(L):
+        tr.tier_counts[s] += int((t == s).sum())
+    for s, v, _ in verdicts:
+        tr.tier_calls[s] += int(v.active.sum().item())
+
+
+@torch.no_grad()
+def generate_hierarchical(draft: DraftRole, tiers: Sequence[VerifyRole], max_steps: Optional[int] = None,
+                          keep_inputs: bool = False) -> HierarchyTrace:
+    """All roles in ONE process (one GPU holds every tier): the reference configuration of the multi-rank run."""
+    L = draft.L
+    assert len(tiers) == L - 1
+    tr = HierarchyTrace(draft.st.tokens, draft.st.seq_len, tier_counts=[0] * L, tier_calls=[0] * L)
+    cap = draft.st.cap
+    limit = max_steps if max_steps is not None else cap + 4
+    while tr.steps < limit:
+        dm = draft.propose()
+        verdicts, esc = [], None
+        rec = dict(draft=dm, tiers={})
+        for t in tiers:
+            v, esc_out = t.verify(dm, esc)
+            if int(v.active.sum().item()) > 0:
+                b_rows, d_rows, d_thr = draft.rows_for(v)
+                tr.rows_shipped += int(b_rows.numel())
+                drawn = t.draw(b_rows, d_rows, d_thr)
+                verdicts.append((t.s, v, drawn))
+                rec["tiers"][t.s] = (v, drawn)
+            esc = esc_out
+            if not bool(esc.escalate.any().item()):
+                break
+        final = draft.assemble(dm, verdicts)
+        rec["final"] = final
+        before = int(draft.st.seq_len.sum().item())
+        draft.commit(dm, final)
+        for t in tiers:
+            t.commit(dm, final)
+        tr.verified_tokens += int(draft.st.seq_len.sum().item()) - before
+        _account(tr, L, final, verdicts)
+        if keep_inputs:
+            tr.records.append(rec)
+        tr.steps += 1
+        if int(draft.st.seq_len.min().item()) >= cap:
+            break
+    tr.fed_tokens = [t.fed_tokens for t in tiers]
+    return tr
+
+
+# ---- roles on different ranks -----------------------------------------------------------------------------
+@dataclass
+class Placement:
+    """Which rank runs which role.  `tiers[s-1]` lists the ranks of verify tier s: one rank, or several when the
+    tier's lm_head is vocab-sharded over them (the first is the tier's leader)."""
+    draft: int
+    tiers: List[List[int]]
+
+    def leader(self, s: int) -> int:
+        return self.tiers[s - 1][0]
+
+    def ranks_of(self, s: int) -> List[int]:
+        return self.tiers[s - 1]
+
+    @staticmethod
+    def for_world(world: int, n_tiers: int = 3) -> "Placement":
+        """BASELINE configs[3] / the reference's configs/qwen3_models.yaml:5-53 (7B [0], 32B [1], 72B TP over the
+        rest): 1 rank holds everything; 2 ranks = {7B + 32B | 72B}; >= 4 ranks = 7B, 32B, 72B sharded over the
+        remaining ranks (4 of them at most, the reference's tensor_parallel_size)."""
+        if n_tiers != 3:
+            raise ValueError("placements are defined for the 7B / 32B / 72B hierarchy")
+        if world == 1:
+            return Placement(0, [[0], [0]])
+        if world == 2:
+            return Placement(0, [[0], [1]])
+        if world == 3:
+            return Placement(0, [[1], [2]])
+        return Placement(0, [[1], list(range(2, min(world, 6)))])
+
+
+class Wire:
+    """Point-to-point movement of the fixed-shape messages between roles; roles that share a rank hand the
+    tensors over directly.  Counts the bytes that really crossed a link."""
+
+    def __init__(self, rank: int, device, group=None):
+        self.rank, self.device, self.group = rank, device, group
+        self.local: Dict[Tuple[str, int, int], List[torch.Tensor]] = {}
+        self.bytes: Dict[str, int] = {}
+
+    def send(self, name: str, tensors: Sequence[torch.Tensor], src: int, dsts: Sequence[int]) -> None:
+        if self.rank != src:
+            return
+        for d in dsts:
+            if d == src:
+                self.local[(name, src, d)] = list(tensors)
+                continue
+            for t in tensors:
+                t = t.contiguous()
+                if t.numel():
+                    dist.send(t, dst=d, group=self.group)
+                    self.bytes[name] = self.bytes.get(name, 0) + t.numel() * t.element_size()
+
+    def recv(self, name: str, like: Sequence[Tuple[Tuple[int, ...], torch.dtype]], src: int) -> List[torch.Tensor]:
+        if self.rank == src:
+            return self.local.pop((name, src, src))
+        out = []
+        for shape, dtype in like:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            if t.numel():
+                dist.recv(t, src=src, group=self.group)
+            out.append(t)
+        return out
+
+
+@torch.no_grad()
+def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[DraftRole], tiers: Dict[int, VerifyRole],
+                          B: int, K: int, L: int, V: int, logits_dtype: torch.dtype, cap: int, device,
+                          max_steps: Optional[int] = None, group=None, keep_inputs: bool = False) -> HierarchyTrace:
+    """One rank of the multi-rank loop.  `draft` is the DraftRole if this rank hosts tier 0, `tiers` maps stage index
+    -> VerifyRole for the verify tiers this rank hosts (leader or vocab shard).  Every rank executes the same step
+    sequence; only the messages listed in the module docstring cross ranks.  The committed stream is identical to
+    generate_hierarchical's for the same seeds (same arithmetic, same uniforms).
+
+    Per step and tier s:  leader(s-1) -> ranks(s): escalate (always, possibly all zero);  if the tier has work:
+    leader(s) -> D: verdict;  D -> ranks(s): draft rows of the stop-with-rejection sequences;  leader(s) -> D: drawn.
+    D learns whether tier s+1 runs from tier s's verdict (active and not stopped), tier s+1 from the escalate
+    message; both are the same data, so every rank takes the same branch."""
+    wire = Wire(rank, device, group)
+    D = placement.draft
+    verify_ranks = sorted({r for t in placement.tiers for r in t})
+    everyone = sorted({D} | set(verify_ranks))
+    state = draft.st if draft is not None else next(iter(tiers.values())).st
+    tr = HierarchyTrace(state.tokens, state.seq_len, tier_counts=[0] * L, tier_calls=[0] * L)
+    limit = max_steps if max_steps is not None else cap + 4
+    i32, f32, f64, u8 = torch.int32, torch.float32, torch.float64, torch.uint8
+    while tr.steps < limit:
+        # ---- tier 0 proposes; the block goes to every rank that hosts a verify tier
+        dm = None
+        if rank == D:
+            dm = draft.propose()
+            wire.send("draft", [dm.tok, dm.lp_d, dm.p0, dm.stop0], D, verify_ranks)
+        if rank in verify_ranks:
+            t_, l_, p_, s_ = wire.recv("draft", [((B, K), i32), ((B, K), f32), ((B,), f64), ((B,), u8)], D)
+            dm = DraftMsg(t_, l_, p_, s_)
+        verdicts = []
+        rec = dict(draft=dm, tiers={})
+        runs_d = bool((dm.stop0 == 0).any().item()) if rank == D else False      # D's view: does the next tier run?
+        esc_out: Optional[EscMsg] = None                                         # what the tier below handed up
+        for s in range(1, L):
+            ranks_s = placement.ranks_of(s)
+            lead = ranks_s[0]
+            esc_in: Optional[EscMsg] = None
+            if s > 1:
+                prev = placement.leader(s - 1)
+                if rank == prev:
+                    wire.send("escalate", [esc_out.escalate, esc_out.p_prev], prev, ranks_s)
+                if rank in ranks_s:
+                    e_, p_ = wire.recv("escalate", [((B,), u8), ((B, s), f64)], prev)
+                    esc_in = EscMsg(e_, p_)
+            v = drawn = None
+            runs_t = False
+            if rank in ranks_s:
+                v, esc_out = tiers[s].verify(dm, esc_in)
+                runs_t = bool(v.active.any().item())
+                if runs_t and rank == lead:
+                    wire.send("verdict", [v.active, v.stop, v.n_acc], lead, [D])
+            if rank == D and runs_d:
+                a_, st_, n_ = wire.recv("verdict", [((B,), i32), ((B,), i32), ((B,), i32)], lead)
+                vd = v if v is not None else Verdict(a_, st_, n_)
+                b_rows, d_rows, d_thr = draft.rows_for(vd)
+                tr.rows_shipped += int(b_rows.numel())
+                wire.send("rows", [d_rows, d_thr], D, ranks_s)
+            if rank in ranks_s and runs_t:
+                b_exp = tiers[s].rows_expected(v)
+                d_rows, d_thr = wire.recv("rows", [((b_exp.numel(), V), logits_dtype), ((b_exp.numel(),), f32)], D)
+                drawn = tiers[s].draw(b_exp, d_rows, d_thr)
+                if rank == lead:
+                    wire.send("drawn", [drawn], lead, [D])
+            if rank == D and runs_d:
+                (dr_,) = wire.recv("drawn", [((B,), i32)], lead)
+                verdicts.append((s, vd, dr_))
+                rec["tiers"][s] = (vd, dr_)
+                runs_d = bool(((vd.active == 1) & (vd.stop == 0)).any().item())
+            elif rank in ranks_s and runs_t:
+                verdicts.append((s, v, drawn))
+                rec["tiers"][s] = (v, drawn)
+        # ---- the final verdict reaches every rank
+        if rank == D:
+            final = draft.assemble(dm, verdicts)
+            wire.send("final", [final.n_acc, final.drawn, final.tier], D, everyone)
+        n_, d_, t_ = wire.recv("final", [((B,), i32), ((B,), i32), ((B,), i32)], D)
+        final = FinalMsg(n_, d_, t_)
+        rec["final"] = final
+        before = int(state.seq_len.sum().item())
+        if draft is not None:
+            draft.commit(dm, final)
+        for t in tiers.values():
+            t.commit(dm, final)
+        tr.verified_tokens += int(state.seq_len.sum().item()) - before
+        _account(tr, L, final, verdicts)
+        if keep_inputs:
+            tr.records.append(rec)
+        tr.steps += 1
+        if int(state.seq_len.min().item()) >= cap:
+            break
+    tr.fed_tokens = [tiers[s].fed_tokens if s in tiers else 0 for s in range(1, L)]
+    tr.bytes_sent = dict(wire.bytes)
+    return tr

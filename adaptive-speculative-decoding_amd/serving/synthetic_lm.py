@@ -115,11 +115,12 @@ class Block(nn.Module):
         return x + self.down(F.silu(self.gate(h)) * self.up(h)), new_cache
 
 
-    def forward_ragged(self, x, pos, kbuf, vbuf, window: int):
+    def forward_ragged(self, x, pos, kbuf, vbuf, window: int, rows=None):
         """Per-sequence positions (N3): x [B, T, D], pos [B, T] int64; kbuf / vbuf [B, Hkv, Tmax, hd] are
         written in place at `pos`, and query (b, t) attends keys j <= pos[b, t] of the first `window` slots.
         Entries past a sequence's committed length are never read before they are rewritten, so rolling a
-        sequence back is a length update on the caller's side."""
+        sequence back is a length update on the caller's side.  rows (int64 [B], optional): the cache rows
+        these B sequences own, when only a subset of the cached sequences is fed (tier escalation)."""
         s = self.s
         B, T, _ = x.shape
         h = self.ln1(x)
@@ -127,10 +128,13 @@ class Block(nn.Module):
         k = self.k(h).view(B, T, s.kv_heads, s.head_dim).transpose(1, 2)
         v = self.v(h).view(B, T, s.kv_heads, s.head_dim).transpose(1, 2)
         q, k = _rope(q, pos, s.rope_theta), _rope(k, pos, s.rope_theta)
-        bidx = torch.arange(B, device=x.device)[:, None].expand(B, T)
+        bidx = (torch.arange(B, device=x.device) if rows is None else rows)[:, None].expand(B, T)
         kbuf[bidx, :, pos] = k.transpose(1, 2)
         vbuf[bidx, :, pos] = v.transpose(1, 2)
-        kk, vv = kbuf[:, :, :window], vbuf[:, :, :window]
+        if rows is None:
+            kk, vv = kbuf[:, :, :window], vbuf[:, :, :window]
+        else:
+            kk, vv = kbuf[:, :, :window].index_select(0, rows), vbuf[:, :, :window].index_select(0, rows)
         rep = s.heads // s.kv_heads
         if rep > 1:
             kk, vv = kk.repeat_interleave(rep, dim=1), vv.repeat_interleave(rep, dim=1)
@@ -187,16 +191,21 @@ class SyntheticLM(nn.Module):
                         for _ in range(self.shape.layers)]
 
     @torch.no_grad()
-    def forward_ragged(self, ids: torch.Tensor, pos0: torch.Tensor, window: int, return_hidden: bool = False):
+    def forward_ragged(self, ids: torch.Tensor, pos0: torch.Tensor, window: int, return_hidden: bool = False,
+                       rows: Optional[torch.Tensor] = None):
         """ids [B, T] placed at positions pos0[b] .. pos0[b]+T-1 of sequence b (pos0: [B] integer tensor);
         `window` is a host-side upper bound on any position in use (no device read-back).  KV entries at
-        those positions are (re)written; nothing else changes.  Returns logits [B, T, V] (or hidden states)."""
+        those positions are (re)written; nothing else changes.  Returns logits [B, T, V] (or hidden states).
+        rows: cache rows of the B sequences when they are a subset of the allocated batch.  Positions past the
+        cache (padding behind a ragged feed) are clamped into its last slot, which no real token ever uses."""
         assert self._ragged is not None, "call alloc_ragged first"
         B, T = ids.shape
-        pos = pos0.to(torch.int64)[:, None] + torch.arange(T, device=ids.device)
+        cap = self._ragged[0][0].shape[2]
+        window = min(window, cap)
+        pos = (pos0.to(torch.int64)[:, None] + torch.arange(T, device=ids.device)).clamp_(max=cap - 1)
         x = self.embed(ids)
         for blk, (kb, vb) in zip(self.blocks, self._ragged):
-            x = blk.forward_ragged(x, pos, kb, vb, window)
+            x = blk.forward_ragged(x, pos, kb, vb, window, rows)
         x = self.norm(x)
         if return_hidden:
             return x

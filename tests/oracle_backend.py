@@ -75,7 +75,7 @@ class OracleOps:
                 torch.from_numpy(r["bits"].view(np.int64)))
 
     def lse_partial(self, logits_shard, tok, v_offset, inv_temperature=1.0):
-        assert inv_temperature == 1.0, "the gloo tests shard at temperature 1"
+        assert inv_temperature == 1.0, "given logits are sharded at temperature 1 in the gloo tests"
         import torch
         store, dt = self._store(logits_shard)
         B, K, V = store.shape
@@ -84,11 +84,18 @@ class OracleOps:
         return torch.from_numpy(msg)
 
     def lm_head_partial(self, hidden, weight_shard, tok, v_offset, inv_temperature=1.0):
-        """f64 product of the bf16 operands, then the shard message of lse_partial on those logits."""
+        """f64 product of the operands, scaled by inv_temperature, then the shard message (m2, s, g) in f64
+        (g is the scaled logit: this ops' accept_from_partials does not rescale)."""
         import torch
-        x = hidden.double().reshape(-1, hidden.shape[-1]) @ weight_shard.double().T
         B, K = tok.shape
-        return self.lse_partial(x.float().reshape(B, K, -1), tok, v_offset, inv_temperature)
+        x = (hidden.double().reshape(B * K, -1) @ weight_shard.double().T).numpy() * float(np.float32(inv_temperature))
+        t = tok.numpy().reshape(-1).astype(np.int64) - v_offset
+        m = x.max(axis=1)
+        s = np.exp(x - m[:, None]).sum(axis=1)
+        inside = (t >= 0) & (t < x.shape[1])
+        g = np.where(inside, x[np.arange(B * K), np.clip(t, 0, x.shape[1] - 1)], -np.inf)
+        msg = np.stack([m / np.log(2.0), s, g], axis=-1).reshape(B, K, 3)
+        return torch.from_numpy(msg)
 
     def accept_from_partials(self, msg_all, lp_d, u, inv_temperature=1.0):
         import torch
@@ -106,3 +113,82 @@ class OracleOps:
         n_acc = np.array([int(np.argmin(np.append(a, 0))) for a in acc], dtype=np.int32)
         bits = np.array([sum(int(a[k]) << k for k in range(K)) for a in acc], dtype=np.int64)
         return torch.from_numpy(lp.astype(np.float32)), torch.from_numpy(acc), torch.from_numpy(n_acc), torch.from_numpy(bits)
+
+
+# ---- the rest of a tier step (asd_amd.serving.hierarchy), by the oracle on CPU tensors ----------------------
+def _np_store(t):
+    import torch
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.contiguous().view(torch.int16).numpy().view(np.uint16), (O.DT_BF16 if t.dtype == torch.bfloat16 else O.DT_F16)
+    return t.float().contiguous().numpy(), O.DT_F32
+
+
+def oracle_predictor_stop(weights, lp, feat, p_hist, stage_idx, costs, lam, risk_adjustment=True, n_obs=100, alpha=1.0,
+                          beta=1.0, stats_col=5):
+    """asd_predictor_stop restated with the oracle's pieces (numpy in / numpy out): A7 stats -> feature overlay ->
+    A8 MLP -> A2 Bayes -> p_hist[:, stage_idx] -> A1 DP rule over all L stages."""
+    w1, b1, w2, b2 = weights
+    lp = np.asarray(lp, dtype=np.float32)
+    x = np.array(feat, dtype=np.float32, copy=True)
+    stats = O.logprob_stats(lp, None, K=lp.shape[1])
+    if stats_col >= 0:
+        x[:, stats_col:stats_col + 5] = stats.astype(np.float32)
+    score = O.mlp_predict(x, w1, b1, np.asarray(w2).reshape(-1), b2)
+    p = score.astype(np.float64)
+    if risk_adjustment:
+        p = O.bayes_adjust(p, n_obs, alpha, beta)
+    hist = np.array(p_hist, dtype=np.float64, copy=True)
+    hist[:, stage_idx] = p
+    k_star, _ = O.optimal_stopping(hist, np.asarray(costs, dtype=np.float64), float(lam))
+    return score, k_star, hist
+
+
+def _extend_oracle_ops():
+    import torch
+
+    def lm_head_verify(self, hidden, weight, tok, lp_d, u, inv_temperature=1.0):
+        """f64 product of the operands as stored (bf16 or f32), then the A5 rule on x * inv_temperature."""
+        B, K = tok.shape
+        x = hidden.double().reshape(B * K, -1).numpy() @ weight.double().numpy().T
+        a = float(np.float32(inv_temperature))
+        lp, acc, n_acc = O.py_verify_accept((x * a).reshape(B, K, -1), tok.numpy(), lp_d.numpy(), u.numpy())
+        bits = np.array([sum(int(f) << k for k, f in enumerate(row)) for row in acc], dtype=np.int64)
+        return (torch.from_numpy(lp.astype(np.float32)), torch.from_numpy(acc), torch.from_numpy(n_acc), torch.from_numpy(bits))
+
+    def pack_predictor(self, predictor, device):
+        return predictor.weights_numpy()
+
+    def predictor_stop(self, pred, lp, feat, p_hist, stage_idx, costs, lam, risk_adjustment=True, n_obs=100, alpha=1.0,
+                       beta=1.0, stats_col=5):
+        score, k_star, hist = oracle_predictor_stop(pred, lp.numpy(), feat.numpy(), p_hist.numpy(), stage_idx,
+                                                    costs.numpy(), lam, risk_adjustment, n_obs, alpha, beta, stats_col)
+        p_hist.copy_(torch.from_numpy(hist))
+        return torch.from_numpy(score), torch.from_numpy(k_star), p_hist
+
+    def draft_sample(self, logits, r, inv_temperature=1.0, top_p=1.0):
+        store, dt = _np_store(logits)
+        B, V = store.shape
+        d = O.draft_sample(store, dt, r.numpy(), B, V, inv_temperature, top_p)
+        return torch.from_numpy(d["tok"]), torch.from_numpy(d["lp"].astype(np.float32)), torch.from_numpy(d["thr"])
+
+    def residual_sample(self, t_logits, d_logits, n_acc, r, bonus, inv_temperature=1.0, d_threshold=None):
+        st, dt = _np_store(t_logits)
+        sd, _ = _np_store(d_logits)
+        sb = None if bonus is None else _np_store(bonus)[0]
+        B, K, V = st.shape
+        tok, _ = O.residual_sample(st.reshape(B * K, V), sd.reshape(B * K, V), dt, n_acc.numpy(), r.numpy(), B, K, V,
+                                   bonus=sb, inv_temperature=inv_temperature,
+                                   d_threshold=None if d_threshold is None else d_threshold.numpy())
+        return torch.from_numpy(tok)
+
+    def commit_step(self, tok, n_acc, drawn, seq_len, tokens, n_commit, max_len):
+        lens, out, nc = O.commit_step(tok.numpy(), n_acc.numpy(), drawn.numpy(), seq_len.numpy(), tokens.numpy(), max_len)
+        seq_len.copy_(torch.from_numpy(lens))
+        tokens.copy_(torch.from_numpy(out))
+        n_commit.copy_(torch.from_numpy(nc))
+
+    for f in (lm_head_verify, pack_predictor, predictor_stop, draft_sample, residual_sample, commit_step):
+        setattr(OracleOps, f.__name__, f)
+
+
+_extend_oracle_ops()

@@ -1,0 +1,172 @@
+"""The three-tier stop-or-escalate loop on the GPU: every launch behind HipOps goes through libasd_hip.so
+(asd_draft_sample, asd_verify_accept / asd_lm_head_verify, asd_predictor_stop, asd_residual_sample_ex,
+asd_commit_step).  BASELINE configs[3] in miniature on one device: tiny draft / tier-1 / tier-2 models.
+
+Checked per step and tier against the oracle ON THE RECORDED INPUTS: accept mask / n_acc (margin-filtered, bit-exact),
+the predictor score (<= 1e-5), p_hist (bit-exact Bayes of the kernel's own score), k* (bit-exact DP on the kernel's
+p_hist), the stop flag, the escalation chain, the committed stream; plus: some sequences stop at tier 1 and others
+escalate.  Reference anchor of the decision: src/serving/pipeline.py:225-266."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+V, B, P, NEW, K = 1000, 6, 5, 24, 4
+
+
+def _build(lam, dtype, heads, min_stage=1):
+    import torch
+    from asd_amd.distributed import HipOps
+    from asd_amd.serving import hierarchy as H
+    from tests.test_hierarchy import _model, _predictor, _prompt
+    cfg = H.HierarchyConfig(draft_len=K, temperature=0.7, top_p=0.9, lambda_value=lam, seed=3, min_verify_stage=min_stage)
+    ops, pred, prompt = HipOps(), _predictor(), _prompt().cuda()
+    d = H.DraftRole(_model(0, 0, dtype, "cuda"), cfg, ops, prompt, NEW, pred)
+    ts = []
+    for s, (noise, seed, hd) in enumerate(zip((0.02, 0.04), (5, 6), heads), start=1):
+        m = _model(noise, seed, dtype, "cuda")
+        head = H.FusedHead(m, ops) if hd == "fused" else H.LogitsHead(m, ops)
+        ts.append(H.VerifyRole(m, s, cfg, ops, prompt, NEW, pred, head=head, keep_inputs=True))
+    torch.cuda.synchronize()
+    return d, ts, cfg, prompt, pred
+
+
+def _run_mixed(dtype, heads):
+    from asd_amd.serving import hierarchy as H
+    for lam in (25.0, 22.0, 28.0, 18.0, 32.0):
+        d, ts, cfg, prompt, pred = _build(lam, dtype, heads)
+        tr = H.generate_hierarchical(d, ts, keep_inputs=True)
+        if tr.tier_counts[1] > 0 and tr.tier_counts[2] > 0:
+            return tr, cfg, prompt, pred
+    raise AssertionError(f"no lambda gave a mixed stop distribution: {tr.tier_counts}")
+
+
+def _store(t):
+    import torch
+    if t.dtype == torch.bfloat16:
+        return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16), O.DT_BF16
+    return t.float().contiguous().cpu().numpy(), O.DT_F32
+
+
+@pytest.mark.parametrize("dtype_name,heads", [("float32", ("logits", "logits")), ("bfloat16", ("logits", "fused"))])
+def test_three_tier_loop_on_gpu_matches_oracle(dtype_name, heads):
+    import torch
+    from tests.oracle_backend import oracle_predictor_stop
+    from tests.test_hierarchy import _model
+    dtype = getattr(torch, dtype_name)
+    tr, cfg, prompt, pred = _run_mixed(dtype, heads)
+    print("tier_counts", tr.tier_counts, "tier_calls", tr.tier_calls, "fed", tr.fed_tokens, "steps", tr.steps)
+    assert 0 < tr.tier_counts[1] < sum(tr.tier_counts) and tr.tier_counts[2] > 0     # 0 < stop rate at tier 1 < 1
+    assert tr.tier_calls[2] < tr.tier_calls[1]
+    assert (tr.seq_len == P + NEW).all()
+    weights = pred.weights_numpy()
+    costs = np.array(cfg.stage_costs)
+    inv_t = np.float32(1 / 0.7)
+    fresh = {1: _model(0.02, 5, dtype, "cuda"), 2: _model(0.04, 6, dtype, "cuda")} if dtype == torch.float32 else None
+    lens = np.full(B, P)
+    buf = np.zeros((B, P + NEW), np.int32)
+    buf[:, :P] = prompt.cpu().numpy()
+    checked_masks = 0
+    for rec in tr.records:
+        dm, final = rec["draft"], rec["final"]
+        expect_active = np.ones(B, bool)
+        p_prev = dm.p0.cpu().numpy()[:, None]
+        # stage 0: the draft tier's own column of p_hist, from ITS log-probs
+        sc0, _, h0 = oracle_predictor_stop(weights, dm.lp_d.cpu().numpy(), tr_feat(rec), np.ones((B, 3)), 0, costs, cfg.lambda_value)
+        np.testing.assert_allclose(p_prev[:, 0], h0[:, 0], atol=2e-5, rtol=0)
+        for s in (1, 2):
+            if s not in rec["tiers"]:
+                continue
+            v, drawn = rec["tiers"][s]
+            idx = v.idx.cpu().numpy()
+            assert np.array_equal(idx, np.nonzero(expect_active)[0])
+            inp, n = v.inputs, len(idx)
+            tok, lp_d, u = (inp[k].cpu().numpy() for k in ("tok", "lp_d", "u"))
+            if "logits" in inp:
+                store, dt = _store(inp["logits"])
+                ref = O.verify_accept(store.reshape(n * K, V), dt, tok, lp_d, u, n, K, V, inv_temperature=inv_t)
+                atol = 1e-5
+            else:                                  # the tier verified from hidden states: f64 GEMM oracle
+                hb = inp["hidden"].reshape(n * K, -1).contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+                wmat = tr_models[s].lm_head.weight
+                wb = wmat.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+                ref = O.lm_head_verify(hb, wb, tok, lp_d, u, n, K, float(np.float32(inv_t * 4.0)))
+                ref["lp_t"] = ref["lp_t64"].astype(np.float32)
+                atol = 2e-4
+            np.testing.assert_allclose(inp["lp_t"].cpu().numpy(), ref["lp_t64"], atol=atol, rtol=1e-6)
+            safe = ref["margin"] >= 10 * atol
+            assert np.array_equal(v.accept.cpu().numpy()[safe], ref["accept"][safe])
+            checked_masks += int(safe.sum())
+            if fresh is not None:                  # KV catch-up of a tier that sat idle: from-scratch forward on the context
+                for i, b in enumerate(idx):
+                    ctx = np.concatenate([buf[b, :lens[b]], tok[i]])
+                    fresh[s].reset()
+                    full = fresh[s](torch.from_numpy(ctx[None, :]).to(torch.int64).cuda())[0]
+                    assert (full[lens[b] - 1: lens[b] - 1 + K] - inp["logits"][i]).abs().max().item() < 2e-3
+            # stop rule on the kernel's OWN lp_t: score within 1e-5, p_hist column = Bayes(score) and k* bit-exact
+            ph = np.ones((n, 3))
+            ph[:, :s] = p_prev[idx, :s]
+            score, _, _ = oracle_predictor_stop(weights, inp["lp_t"].cpu().numpy(), inp["feat"].cpu().numpy(), ph, s, costs,
+                                                cfg.lambda_value)
+            got_score = v.score.cpu().numpy()
+            np.testing.assert_allclose(got_score, score, atol=1e-5, rtol=0)
+            hist = v.p_hist.cpu().numpy()
+            assert hist[:, :s].tobytes() == ph[:, :s].tobytes()                       # carried columns untouched
+            assert hist[:, s].tobytes() == O.bayes_adjust(got_score.astype(np.float64), cfg.n_obs).tobytes()
+            ks, _ = O.optimal_stopping(hist, costs, cfg.lambda_value)
+            assert np.array_equal(v.k_star.cpu().numpy(), ks)
+            stop = np.ones(n, bool) if s == 2 else (ks <= s)
+            assert np.array_equal(v.stop.cpu().numpy()[idx].astype(bool), stop)
+            nxt = np.ones((B, s + 1))
+            nxt[idx] = hist[:, :s + 1]
+            p_prev = nxt
+            expect_active = np.zeros(B, bool)
+            expect_active[idx[~stop]] = True
+            fin_t, fin_n, fin_d = (x.cpu().numpy() for x in (final.tier, final.n_acc, final.drawn))
+            n_acc = v.n_acc.cpu().numpy()
+            for i, b in enumerate(idx):
+                if stop[i]:
+                    assert fin_t[b] == s and fin_n[b] == n_acc[b] and fin_d[b] == drawn.cpu().numpy()[b]
+                    assert 0 <= fin_d[b] < V
+        tokc = dm.tok.cpu().numpy()
+        for b in range(B):
+            new = (list(tokc[b, :int(final.n_acc[b])]) + [int(final.drawn[b])])[: max(0, P + NEW - lens[b])]
+            buf[b, lens[b]:lens[b] + len(new)] = new
+            lens[b] += len(new)
+    assert np.array_equal(buf, tr.tokens.cpu().numpy())
+    assert checked_masks > 50
+
+
+def tr_feat(rec):
+    """prompt features are the same for every step: recompute from the prompt like DraftRole does."""
+    from asd_amd.serving.hierarchy import prompt_features
+    from tests.test_hierarchy import _prompt
+    return prompt_features(_prompt()).numpy()
+
+
+tr_models = {}
+
+
+@pytest.fixture(autouse=True)
+def _tier_models():
+    """The fused-head check needs tier 2's lm_head matrix: same construction as _build."""
+    import torch
+    from tests.test_hierarchy import _model
+    tr_models[1] = _model(0.02, 5, torch.bfloat16, "cuda")
+    tr_models[2] = _model(0.04, 6, torch.bfloat16, "cuda")
+    yield
+    tr_models.clear()
+
+
+def test_stage0_cascade_and_lambda_extremes_on_gpu():
+    import torch
+    from asd_amd.serving import hierarchy as H
+    for lam, min_stage, check in ((2.0, 1, lambda t: t.tier_counts[2] == 0 and t.tier_counts[1] > 0),
+                                  (60.0, 1, lambda t: t.tier_counts[1] == 0 and t.tier_counts[2] > 0),
+                                  (2.0, 0, lambda t: t.tier_counts[0] > 0)):
+        d, ts, cfg, prompt, pred = _build(lam, torch.bfloat16, ("logits", "logits"), min_stage)
+        tr = H.generate_hierarchical(d, ts)
+        assert check(tr), (lam, min_stage, tr.tier_counts)
+        assert (tr.seq_len == P + NEW).all()
