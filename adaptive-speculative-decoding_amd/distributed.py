@@ -114,9 +114,32 @@ class HipOps:
     def commit_step(self, tok, n_acc, drawn, seq_len, tokens, n_commit, max_len):
         self.K.commit_step(tok, n_acc, drawn, seq_len, tokens, n_commit, max_len=max_len)
 
+    def lambda_sweep(self, p_hist, costs, lams):
+        """N4: the DP rule for every (lambda, sequence) pair in one launch -> k_star [G, n] i32."""
+        return self.K.lambda_sweep(p_hist, costs, lams)[0]
+
 
 def _world(group) -> Tuple[int, int]:
     return dist.get_world_size(group), dist.get_rank(group)
+
+
+def host_staged(group=None) -> bool:
+    """True when the group's backend cannot move device tensors itself (gloo: the CPU tests, and the one-GPU
+    rehearsal of the multi-rank paths); messages are then staged through host memory.  RCCL moves them directly."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_gather_any(parts_like: torch.Tensor, group=None):
+    """all_gather of equally shaped tensors -> list in rank order; device tensors over gloo go through the host."""
+    world = dist.get_world_size(group)
+    if parts_like.is_cuda and host_staged(group):
+        src = parts_like.cpu()
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src, group=group)
+        return [p.to(parts_like.device) for p in parts]
+    parts = [torch.empty_like(parts_like) for _ in range(world)]
+    dist.all_gather(parts, parts_like.contiguous(), group=group)
+    return parts
 
 
 class VocabShardedVerifier:
@@ -149,8 +172,7 @@ class VocabShardedVerifier:
         return self._finish(msg, lp_d, u)
 
     def _finish(self, msg, lp_d, u):
-        parts = [torch.empty_like(msg) for _ in range(self.world)]
-        dist.all_gather(parts, msg, group=self.group)          # the one exchange step: [B,K,3] per rank
+        parts = all_gather_any(msg, self.group)                # the one exchange step: [B,K,3] per rank
         return self.ops.accept_from_partials(torch.stack(parts).contiguous(), lp_d, u, self.inv_temperature)
 
 

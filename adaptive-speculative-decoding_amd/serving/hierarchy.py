@@ -47,7 +47,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ..distributed import HipOps, shard_bounds
+from ..distributed import HipOps, all_gather_any, host_staged, shard_bounds
 
 
 @dataclass
@@ -279,8 +279,7 @@ class ShardedHead:
                     for r in range(self.world))
         pad = torch.zeros((piece.shape[0], width), dtype=piece.dtype, device=piece.device)
         pad[:, :piece.shape[1]] = piece
-        parts = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(parts, pad, group=self.group)
+        parts = all_gather_any(pad, self.group)
         self.bytes_exchanged += pad.numel() * pad.element_size() * (self.world - 1)
         cols = [p[:, :shard_bounds(self.vocab, self.world, r)[1] - shard_bounds(self.vocab, self.world, r)[0]]
                 for r, p in enumerate(parts)]
@@ -418,6 +417,31 @@ class VerifyRole:
         self._fed = self._pending = None                    # a step in which this tier is not called feeds nothing
 
 
+def calibrate_lambda(ops, p_hist: torch.Tensor, costs: torch.Tensor, stage_idx: int, target_stop_rate: float,
+                     lo: float = 0.05, hi: float = 500.0, grid: int = 256, rounds: int = 4) -> Tuple[float, float]:
+    """A lambda controller over the device-side sweep (N4; the reference tunes lambda offline with
+    algorithms/optimizer.py:47-205): given the p_hist rows [n, L] of blocks judged up to `stage_idx` (columns above
+    it at their prior 1.0), each round is ONE asd_lambda_sweep launch that evaluates the DP rule for `grid`
+    log-spaced lambdas; the share of blocks with k* <= stage_idx falls as lambda grows, and the next round refines
+    the bracket in which it crosses `target_stop_rate` (scores of similar blocks differ in the 4th digit, so one
+    coarse grid would only ever see "all stop" / "none stops").  Returns (lambda, share at that lambda)."""
+    best_lam, best_share = lo, 1.0
+    for _ in range(rounds):
+        lams = torch.logspace(np.log10(lo), np.log10(hi), grid, dtype=torch.float64, device=p_hist.device)
+        k = ops.lambda_sweep(p_hist.contiguous(), costs, lams)                    # [G, n]
+        share = (k <= stage_idx).to(torch.float64).mean(dim=1)
+        i = int((share - target_stop_rate).abs().argmin().item())
+        best_lam, best_share = float(lams[i].item()), float(share[i].item())
+        if abs(best_share - target_stop_rate) <= 0.5 / max(1, p_hist.shape[0]):
+            break
+        above = (share >= target_stop_rate).nonzero()                              # lambdas that still stop enough blocks
+        j = int(above.max().item()) if above.numel() else 0
+        if j + 1 >= grid:
+            break
+        lo, hi = float(lams[j].item()), float(lams[j + 1].item())
+    return best_lam, best_share
+
+
 # ------------------------------------------------------------------------------------------- drivers
 @dataclass
 class HierarchyTrace:
@@ -523,6 +547,7 @@ class Wire:
 
     def __init__(self, rank: int, device, group=None):
         self.rank, self.device, self.group = rank, device, group
+        self.staged = dist.is_initialized() and host_staged(group) and torch.device(device).type == "cuda"
         self.local: Dict[Tuple[str, int, int], List[torch.Tensor]] = {}
         self.bytes: Dict[str, int] = {}
 
@@ -536,7 +561,7 @@ class Wire:
             for t in tensors:
                 t = t.contiguous()
                 if t.numel():
-                    dist.send(t, dst=d, group=self.group)
+                    dist.send(t.cpu() if (t.is_cuda and self.staged) else t, dst=d, group=self.group)
                     self.bytes[name] = self.bytes.get(name, 0) + t.numel() * t.element_size()
 
     def recv(self, name: str, like: Sequence[Tuple[Tuple[int, ...], torch.dtype]], src: int) -> List[torch.Tensor]:
@@ -544,10 +569,11 @@ class Wire:
             return self.local.pop((name, src, src))
         out = []
         for shape, dtype in like:
-            t = torch.empty(shape, dtype=dtype, device=self.device)
+            dev = "cpu" if self.staged else self.device
+            t = torch.empty(shape, dtype=dtype, device=dev)
             if t.numel():
                 dist.recv(t, src=src, group=self.group)
-            out.append(t)
+            out.append(t.to(self.device))
         return out
 
 
@@ -645,3 +671,50 @@ def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[Draft
     tr.fed_tokens = [tiers[s].fed_tokens if s in tiers else 0 for s in range(1, L)]
     tr.bytes_sent = dict(wire.bytes)
     return tr
+
+
+# ---- construction helper shared by bench.py, tools/ and the tests --------------------------------------------
+def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: HierarchyConfig, prompt_ids: torch.Tensor,
+                     max_new_tokens: int, predictor, ops=None, dtype: torch.dtype = torch.bfloat16,
+                     heads: Sequence[str] = ("logits", "fused"), logit_scale: float = 1.0, seeds: Sequence[int] = (1, 2, 3),
+                     keep_inputs: bool = False, weight_noise: Sequence[float] = (0.0, 0.0, 0.0), share_seed: Optional[int] = None
+                     ) -> Tuple[Optional[DraftRole], Dict[int, VerifyRole]]:
+    """The roles `rank` hosts under `placement`: tier 0 + verify tiers, models built on prompt_ids.device.
+    shapes: one synthetic_lm.LMShape per tier.  heads[s-1]: "logits" (lm_head GEMM + asd_verify_accept), "fused"
+    (asd_lm_head_verify from hidden states); a tier placed on several ranks gets a ShardedHead over those ranks
+    (every rank of the tier must call this function: it creates the tier's process group).
+    share_seed: all tiers start from the same seed (+ per-tier lm_head noise `weight_noise`) -- small test models
+    that agree often enough to accept tokens."""
+    from .synthetic_lm import SyntheticLM
+    ops = ops if ops is not None else HipOps()
+    dev = prompt_ids.device
+    L = len(cfg.stage_costs)
+    assert len(shapes) == L
+
+    def make(i):
+        m = SyntheticLM(shapes[i], dtype=dtype, device=dev, seed=share_seed if share_seed is not None else seeds[i],
+                        logit_scale=logit_scale)
+        if weight_noise[i]:
+            g = torch.Generator(device=dev).manual_seed(1000 + i)
+            with torch.no_grad():
+                w = m.lm_head.weight
+                w.add_((torch.randn(w.shape, generator=g, device=dev) * weight_noise[i]).to(w.dtype))
+        return m
+
+    draft = DraftRole(make(0), cfg, ops, prompt_ids, max_new_tokens, predictor) if rank == placement.draft else None
+    tiers: Dict[int, VerifyRole] = {}
+    for s in range(1, L):
+        ranks_s = placement.ranks_of(s)
+        group = dist.new_group(ranks_s) if len(ranks_s) > 1 else None          # collective: every rank calls it
+        if rank not in ranks_s:
+            continue
+        m = make(s)
+        if len(ranks_s) > 1:
+            head = ShardedHead(m, ops, shapes[s].vocab, group=group)
+            m.lm_head.weight = torch.nn.Parameter(m.lm_head.weight[head.v0:head.v1].clone(), requires_grad=False)
+        elif heads[s - 1] == "fused":
+            head = FusedHead(m, ops)
+        else:
+            head = LogitsHead(m, ops)
+        tiers[s] = VerifyRole(m, s, cfg, ops, prompt_ids, max_new_tokens, predictor, head=head, keep_inputs=keep_inputs)
+    return draft, tiers

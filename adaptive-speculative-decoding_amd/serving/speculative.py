@@ -8,9 +8,10 @@ arithmetic:
   target tier  scores the K drafted positions in one forward: logits_t [B, K(+1), V]
   verify       asd_verify_accept: lp_t, accept[b,k] = log u <= lp_t - lp_d, n_acc[b], ballot word
   stop         asd_predictor_stop: log-prob statistics of the K target log-probs -> feature columns
-               [5:10] -> quality predictor -> Bayes adjustment -> DP stop rule over the tiers:
-               stop[b] says whether tier `stage_idx`'s verification is final for sequence b or
-               the step should be re-verified by the next (larger) tier.
+               [5:10] -> quality predictor -> Bayes adjustment -> DP stop rule over the tiers.  The loops in
+               THIS module have one verifying tier, so they only record the decision; the loop in which it
+               acts -- sequences whose k* lies above the current tier are re-verified by the next tier -- is
+               serving/hierarchy.py.
   commit       n_acc accepted tokens + one token from the target: asd_residual_sample draws it from the
                residual distribution max(0, p_t - p_d) at the first rejection, or from the target's own
                next-token distribution when all K pass.
@@ -19,9 +20,10 @@ arithmetic:
 space, packed predictor weights, stage costs, history of adjusted probabilities.  Everything it
 does per step is two launches through the C ABI; no host synchronisation.
 
-`speculative_generate` drives two `SyntheticLM`s through the loop.  That part is PLUMBING (model
-execution is third-party in the reference): plain torch sampling, lock-step commit of
-min_b(n_acc)+1 tokens so the batch shares one KV length.
+`speculative_generate` drives two `SyntheticLM`s through the loop.  Model execution is PLUMBING
+(third-party in the reference); the proposal draw (asd_draft_sample), the verify step and the commit
+draw (asd_residual_sample_ex) are kernels.  Lock-step commit of min_b(n_acc)+1 tokens so the batch
+shares one KV length; `speculative_generate_ragged` commits per sequence.
 """
 from __future__ import annotations
 
@@ -58,7 +60,9 @@ class SpeculativeVerifier:
         self.fused = bool(fused)          # one launch per step (asd_verify_accept_fused) instead of two
         self.inv_temperature = 1.0        # sampling temperature of the tier pair, fused into the verify pass
         self.p_hist = torch.ones((batch, self.L), dtype=torch.float64, device=self.device)
-        self.sampler = K.ResidualSampler(batch, vocab, logits_dtype, self.device)   # commit step (asd_residual_sample)
+        self.sampler = K.ResidualSampler(batch, vocab, logits_dtype, self.device)   # commit step (asd_residual_sample_ex)
+        self.draft_sampler = K.DraftSampler(batch, vocab, logits_dtype, self.device)  # proposal step (asd_draft_sample)
+        self.top_p = 1.0                  # nucleus of the draft tier (reference: 0.9, generate_training_data.py:110-119)
         self.in_dim = self.hidden = 0
         self.packed = None
         self._lm_head = None              # (key, kernels.LmHeadVerifier) of the last verify_hidden call
@@ -119,11 +123,14 @@ class SpeculativeVerifier:
 
 
 # ------------------------------------------------------------------------------------ plumbing
-def _sample(logits: torch.Tensor, temperature: float, gen: torch.Generator):
-    """logits [B,V] -> (tok [B] int64, log q(tok) [B] f32) under softmax(logits / T)."""
-    lp = torch.log_softmax(logits.float() / temperature, dim=-1)
-    tok = torch.multinomial(lp.exp(), 1, generator=gen)[:, 0]
-    return tok, lp.gather(1, tok[:, None])[:, 0]
+def _propose(verifier: "SpeculativeVerifier", logits: torch.Tensor, gen: torch.Generator):
+    """X1: logits [B,V] -> (tok [B] int64, log q(tok) [B] f32, nucleus threshold [B] f32) under the draft tier's
+    softmax(logits / T) truncated to its top-p nucleus -- one asd_draft_sample call (the reference delegates this to
+    HF generate(do_sample=True, temperature=0.7, top_p=0.9), generate_training_data.py:110-119)."""
+    logits = logits.contiguous()
+    r = torch.rand((logits.shape[0],), generator=gen, device=logits.device)
+    d = verifier.draft_sampler(logits, r, verifier.inv_temperature, verifier.top_p)
+    return d.tok.to(torch.int64), d.lp, d.thr
 
 
 @dataclass
@@ -155,16 +162,18 @@ def speculative_generate(draft, target, prompt_ids: torch.Tensor, max_new_tokens
     steps = verified = produced = 0
     while produced < max_new_tokens:
         base = seq.shape[1]
-        toks, lps, dls, dl = [], [], [], d_logits
+        toks, lps, dls, thrs, dl = [], [], [], [], d_logits
         for k in range(Kd):                         # draft K tokens autoregressively
-            t, lp = _sample(dl, temperature, gen)
+            t, lp, thr = _propose(verifier, dl, gen)
             toks.append(t)
             lps.append(lp)
+            thrs.append(thr)
             dls.append(dl)                          # kept for the residual distribution at a rejection
             if k + 1 < Kd:
                 dl = draft(t[:, None])[:, -1]
         tok = torch.stack(toks, 1)
         lp_d = torch.stack(lps, 1).contiguous()
+        d_thr = torch.stack(thrs, 1).contiguous()
         t_new = target(tok)                         # [B, K, V]: row k scores the token AFTER draft token k
         # logits that score draft position k: k = 0 -> t_last, k > 0 -> t_new[:, k-1]
         score = torch.cat([t_last[:, None], t_new[:, :-1]], dim=1).contiguous()   # raw logits: no scaling pass
@@ -176,7 +185,8 @@ def speculative_generate(draft, target, prompt_ids: torch.Tensor, max_new_tokens
         # bonus draw from the target's next-token logits when all K passed -- one call, raw logits in
         r = torch.rand((B,), generator=gen, device=dev)
         drawn = verifier.sampler(score, torch.stack(dls, 1).to(score.dtype).contiguous(), res.verify.n_acc, r,
-                                 bonus_logits=t_new[:, -1].contiguous(), inv_temperature=verifier.inv_temperature)
+                                 bonus_logits=t_new[:, -1].contiguous(), inv_temperature=verifier.inv_temperature,
+                                 d_threshold=d_thr)
         drawn = drawn.to(torch.int64)
         if m - 1 == Kd:                             # every sequence accepted all K: K drafts + the bonus token
             commit = torch.cat([tok, drawn[:, None]], 1)
@@ -262,14 +272,15 @@ def speculative_generate_ragged(draft, target, prompt_ids: torch.Tensor, max_new
         window = min(P + steps * (Kd + 1) + Kd + 1, cap + Kd + 2)    # host-side bound on every position touched this step
         last2 = torch.stack([tokens[rows, L - 2], tokens[rows, L - 1]], 1).to(torch.int64)
         dl = draft.forward_ragged(last2, L - 2, window)[:, -1]
-        toks, lps, dls = [], [], []
+        toks, lps, dls, thrs = [], [], [], []
         for k in range(Kd):
             if greedy_hidden:
-                t, lp = dl.argmax(-1), torch.zeros((B,), device=dev)
+                t, lp, thr = dl.argmax(-1), torch.zeros((B,), device=dev), None
             else:
-                t, lp = _sample(dl, temperature, gen)
+                t, lp, thr = _propose(verifier, dl, gen)
             toks.append(t)
             lps.append(lp)
+            thrs.append(thr)
             dls.append(dl)
             if k + 1 < Kd:
                 dl = draft.forward_ragged(t[:, None], L + k, window)[:, -1]
@@ -303,7 +314,8 @@ def speculative_generate_ragged(draft, target, prompt_ids: torch.Tensor, max_new
         res = verifier.step(score, tok32, lp_d, u, feat)
         r = torch.rand((B,), generator=gen, device=dev)
         drawn = verifier.sampler(score, torch.stack(dls, 1).to(score.dtype).contiguous(), res.verify.n_acc, r,
-                                 bonus_logits=t_out[:, Kd].contiguous(), inv_temperature=verifier.inv_temperature)
+                                 bonus_logits=t_out[:, Kd].contiguous(), inv_temperature=verifier.inv_temperature,
+                                 d_threshold=torch.stack(thrs, 1).contiguous())
         K.commit_step(tok32, res.verify.n_acc, drawn, seq_len, tokens, n_commit, max_len=cap)
         verified += n_commit.sum()
         masks.append(res.verify.accept.clone())

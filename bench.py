@@ -163,6 +163,147 @@ def load_traffic():
         return None, None
 
 
+# ------------------------------------------------------------------------------------------------------------
+# The token-level LOOP around the hot path: 7B draft -> 32B -> 72B with the optimal-stopping rule live
+# (serving/hierarchy.py; BASELINE configs[2..3]).  Model execution is synthetic random-weight Qwen2.5-shape torch
+# modules (third-party in the reference): the numbers below are CONTEXT for the kernel-step rate, not the headline.
+def _timed_ops(torch):
+    """HipOps whose calls are bracketed by HIP events (hot-path share of a loop step; a pair costs a few us)."""
+    from asd_amd.distributed import HipOps
+
+    class TimedOps(HipOps):
+        def __init__(self):
+            super().__init__()
+            self.events = {}
+
+        def _t(self, name, fn, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.events.setdefault(name, []).append((e0, e1))
+            return out
+
+        def totals_ms(self):
+            torch.cuda.synchronize()
+            out = {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.events.items()}
+            self.events = {}
+            return out
+
+    for name in ("verify_accept", "lm_head_verify", "lm_head_partial", "accept_from_partials", "predictor_stop",
+                 "draft_sample", "residual_sample", "commit_step"):
+        def wrap(name=name):
+            base = getattr(HipOps, name)
+
+            def f(self, *a, **k):
+                return self._t(name, lambda: base(self, *a, **k))
+            return f
+        setattr(TimedOps, name, wrap())
+    return TimedOps()
+
+
+def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, warmup, steps, heads=("logits", "fused"),
+                   logit_scale=0.6, target_stop_rate=0.66, lam=None, seed=5):
+    """Run `warmup` + `steps` steps of the three-tier stop-or-escalate loop under Placement.for_world(world) and
+    return the record (rank 0) -- timed like the headline: barrier + synchronize on both sides, max over ranks."""
+    from asd_amd.minimal_adaptive_decoder import MinimalQualityPredictor
+    from asd_amd.serving import hierarchy as H
+    from asd_amd.serving.synthetic_lm import QWEN25_SHAPES, tiny
+
+    table = dict(QWEN25_SHAPES, tiny=tiny())
+    shp = [table[n] for n in shapes]
+    V = shp[0].vocab
+    pl = H.Placement.for_world(world)
+    torch.manual_seed(0)
+    pred = MinimalQualityPredictor().eval()
+    with torch.no_grad():
+        for p_ in pred.parameters():
+            p_.mul_(3.0)                    # random-init predictor, scores spread over (0, 1); no trained checkpoint offline
+    new_tokens = (warmup + steps + 3) * (K + 1)
+    g = torch.Generator(device=device).manual_seed(seed)
+    prompt = torch.randint(0, V, (B, prompt_len), generator=g, device=device)
+    cfg = H.HierarchyConfig(draft_len=K, temperature=0.7, top_p=0.9, lambda_value=lam if lam else 1.0e6, seed=seed)
+    ops = _timed_ops(torch)
+    t0 = time.perf_counter()
+    draft, tiers = H.build_rank_roles(rank, pl, shp, cfg, prompt, new_tokens, pred, ops=ops, heads=heads,
+                                      logit_scale=logit_scale, seeds=(1, 2, 3))
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    L = len(shp)
+    red = torch.device("cpu") if (world > 1 and dist.get_backend() == "gloo") else device   # gloo: one-GPU rehearsal
+
+    def run(n):
+        if world == 1:
+            return H.generate_hierarchical(draft, [tiers[s] for s in range(1, L)], max_steps=n)
+        return H.run_hierarchical_rank(rank, pl, draft, tiers, B, K, L, V, torch.bfloat16, prompt_len + new_tokens, device,
+                                       max_steps=n)
+
+    def barrier():
+        if world > 1:
+            dist.all_reduce(torch.zeros(1, device=red))
+
+    active = draft is not None or bool(tiers)
+    calib = None
+    if lam is None:
+        # one probe step with lambda = 1e6 (every block escalates to the top) records p_hist of all B blocks at tier 1;
+        # the lambda controller then picks the lambda whose tier-1 stop share is closest to the target
+        share = 0.0
+        if active:
+            if world == 1:
+                tr0 = H.generate_hierarchical(draft, [tiers[s] for s in range(1, L)], max_steps=1, keep_inputs=True)
+            else:
+                tr0 = H.run_hierarchical_rank(rank, pl, draft, tiers, B, K, L, V, torch.bfloat16, prompt_len + new_tokens,
+                                              device, max_steps=1, keep_inputs=True)
+        lam_t = torch.zeros(2, dtype=torch.float64, device=red)
+        if 1 in tiers and rank == pl.leader(1):
+            v1 = tr0.records[0]["tiers"][1][0]
+            lam_v, share = H.calibrate_lambda(ops, v1.p_hist, tiers[1].costs, 1, target_stop_rate)
+            lam_t[0], lam_t[1] = lam_v, share
+        if world > 1:
+            dist.broadcast(lam_t, src=pl.leader(1))
+        lam_v, share = float(lam_t[0].item()), float(lam_t[1].item())
+        for role in ([draft] if draft is not None else []) + list(tiers.values()):
+            role.cfg.lambda_value = lam_v
+        cfg.lambda_value = lam_v
+        calib = {"target_tier1_stop_rate": target_stop_rate, "probe_share": share,
+                 "how": "one probe step at lambda=1e6, then asd_lambda_sweep over 256 log-spaced lambdas on the probe's p_hist"}
+    if active and warmup:
+        run(warmup)
+    ops.totals_ms()
+    for t in tiers.values():
+        t.fed_tokens = 0
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr = run(steps) if active else None
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hot = ops.totals_ms()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != pl.draft:
+        return None
+    hot_ms = sum(v[0] for v in hot.values())
+    rec = {
+        "tiers": [s.name for s in shp], "placement": {"draft": pl.draft, "tiers": pl.tiers, "ranks": world},
+        "heads": list(heads), "batch": B, "draft_len": K, "prompt_len": prompt_len, "steps": tr.steps, "warmup": warmup,
+        "verified_tokens": tr.verified_tokens, "seconds": elapsed, "verified_tokens_per_s": tr.verified_tokens / elapsed,
+        "ms_per_step": 1e3 * elapsed / max(1, tr.steps), "tokens_per_sequence_step": tr.verified_tokens / max(1, tr.steps * B),
+        "lambda": cfg.lambda_value, "lambda_calibration": calib, "stage_costs": list(cfg.stage_costs),
+        "tier_counts": tr.tier_counts, "stop_rate": tr.stop_rate, "tier_calls": tr.tier_calls,
+        "fed_tokens": tr.fed_tokens, "draft_rows_shipped": tr.rows_shipped, "bytes_sent_from_draft_rank": tr.bytes_sent,
+        "hot_path_ms_per_step_on_draft_rank": hot_ms / max(1, tr.steps),
+        "hot_path_calls": {k: {"ms": v[0], "calls": v[1]} for k, v in hot.items()},
+        "hot_path_share": hot_ms / (1e3 * elapsed), "build_s": build_s,
+        "models": "synthetic random-weight Qwen2.5 shapes (torch / hipBLASLt; third-party in the reference), logit_scale "
+                  f"{logit_scale} so that unrelated random models still accept tokens; KV per sequence (ragged)",
+    }
+    return rec
+
+
 LM_HEADS = {"7b": 3584, "14b": 5120, "32b": 5120, "72b": 8192}   # Qwen2.5 hidden sizes (configs/models.yaml)
 MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16
 
@@ -298,6 +439,74 @@ def main_lm_head(args):
         dist.destroy_process_group()
 
 
+def main_tiers(args):
+    """`--placement tiers`: the timed step is ONE step of the three-tier loop (draft K tokens, tier-1 verify, stop rule,
+    escalated blocks re-verified by tier 2, residual / bonus draw, per-sequence commit) with the tiers placed over the
+    ranks; value = committed tokens per second of the whole job.  The roofline object is still the verify kernel's,
+    measured on rank 0 on a resident c3-shaped buffer."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from asd_amd import kernels as Kmod
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if os.environ.get("ASD_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.dist_backend, **({"device_id": device} if args.dist_backend == "nccl" else {}))
+    B, K, V, desc = WORKLOADS[args.workload]
+    B = args.loop_batch
+    steps = args.steps if args.steps != 1000 else 8
+    warmup = args.warmup if args.warmup != 300 else 2
+    rec = hierarchy_loop(torch, dist, device, rank, world, args.tier_shapes.split(","), B, K, 32, warmup, steps, lam=args.lam,
+                         target_stop_rate=args.stop_rate)
+    if rank == 0:
+        torch.cuda.empty_cache()
+        nbuf = 3
+        ws, bufs = build_inputs(torch, Kmod, B, K, V, nbuf, device, seed=1234)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def verify(buf):
+            Kmod.verify_accept(buf["logits"], buf["tok"], buf["lp_d"], buf["u"], ws, buf["out"])
+        for i in range(600):
+            verify(bufs[i % nbuf])
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(200):
+            verify(bufs[i % nbuf])
+        e1.record()
+        torch.cuda.synchronize()
+        kern_ms = e0.elapsed_time(e1) / 200
+        nbytes = algorithmic_bytes(B, K, V)
+        out = {
+            "metric": "verified_tokens_per_s", "value": rec["verified_tokens_per_s"], "unit": "tokens/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"tiers: token-level loop, {'/'.join(rec['tiers'])} placed over {world} rank(s), batch {B}, "
+                                   f"draft_len {K}, vocab {V}; step = draft K tokens (asd_draft_sample) + tier verify "
+                                   "(asd_verify_accept / asd_lm_head_verify) + asd_predictor_stop + escalation + "
+                                   "asd_residual_sample_ex + asd_commit_step; synthetic random-weight models",
+                       "batch": B, "draft_len": K, "vocab": V, "parallelism": f"tiers over {world} rank(s)",
+                       "placement": rec["placement"]},
+            "roofline": {"bound": "hbm", "achieved": nbytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": nbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "asd::k_verify (verify_accept.hip)", "algorithmic_bytes": nbytes, "kernel_ms_mean": kern_ms,
+                         "timing": "HIP events around 200 back-to-back verify launches on rank 0 after the loop (3 rotating buffers)"},
+            "loop": rec,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,9 +535,23 @@ def main():
                     help="gloo + ASD_BENCH_ONE_DEVICE=1 rehearses the N>1 control flow with every rank on cuda:0")
     ap.add_argument("--lm-head", choices=sorted(LM_HEADS), default=None,
                     help="start the step from hidden states: asd_lm_head_verify with this Qwen2.5 lm_head size (N2)")
+    ap.add_argument("--placement", choices=["replicas", "tiers"], default="replicas",
+                    help="replicas (default): every rank runs the kernel step on its own batch (the headline metric, weak "
+                         "scaling).  tiers: the token-level loop with the 7B / 32B / 72B hierarchy placed over the ranks "
+                         "(BASELINE configs[3]; 1 rank: all on one GPU, 2: {7B+32B | 72B}, >= 4: 7B | 32B | 72B with a "
+                         "vocab-sharded lm_head), stop rule live, small messages point-to-point over RCCL")
+    ap.add_argument("--tier-shapes", default="7b,32b,72b", help="Qwen2.5 shapes of the tiers (or tiny,tiny,tiny)")
+    ap.add_argument("--loop-batch", type=int, default=32)
+    ap.add_argument("--loop-steps", type=int, default=6, help="steps of the bounded `loop` sub-record of the default run")
+    ap.add_argument("--no-loop", action="store_true", help="skip the bounded 7B/32B/72B loop sub-record")
+    ap.add_argument("--lam", type=float, default=None, help="lambda of the loop (default: calibrated to --stop-rate)")
+    ap.add_argument("--stop-rate", type=float, default=0.66, help="target share of blocks whose tier-1 verdict is final "
+                    "(the reference reports 66.2 %% of requests served by its first stage, README.md:91-94)")
     args = ap.parse_args()
     if args.lm_head:
         return main_lm_head(args)
+    if args.placement == "tiers":
+        return main_tiers(args)
 
     import numpy as np
     import torch
@@ -525,7 +748,7 @@ def main():
     # kernel-only figures for the other BASELINE shapes (not bench lines: context for the roofline)
     others = {}
     if rank == 0 and world == 1 and not args.no_other_workloads:
-        del bufs
+        bufs = None
         torch.cuda.empty_cache()
         for name in sorted(WORKLOADS):
             if name == args.workload:
@@ -557,6 +780,20 @@ def main():
                             "achieved_GBs": ob / (oms * 1e-3) / 1e9, "frac_of_8TBs": ob / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             del obufs, ows
             torch.cuda.empty_cache()
+
+    loop_rec = None
+    if world == 1 and not args.no_loop:
+        # bounded sub-record: the full token-level loop around the hot path (7B draft / 32B / 72B on this one GPU,
+        # stop rule live), so that "verified tokens/s, 7B-draft/72B-target" has driver-run evidence beside the
+        # kernel-step rate.  Never part of `value`.
+        try:
+            bufs = None                       # release the rotating logits buffers
+            torch.cuda.empty_cache()
+            loop_rec = hierarchy_loop(torch, dist, device, rank, world, args.tier_shapes.split(","), args.loop_batch, K,
+                                      32, 2, args.loop_steps, lam=args.lam, target_stop_rate=args.stop_rate)
+        except Exception as e:  # noqa: BLE001  (the headline must not depend on the context record)
+            loop_rec = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
 
     if rank == 0:
         achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
@@ -597,6 +834,8 @@ def main():
         }
         if others:
             out["roofline"]["other_workloads_kernel_only"] = others
+        if loop_rec is not None:
+            out["loop"] = loop_rec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, torch, cpu_buf, B, K, V, weights, feat_np, args.cpu_budget_s)
         print(json.dumps(out), flush=True)

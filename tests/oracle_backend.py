@@ -187,7 +187,10 @@ def _extend_oracle_ops():
         tokens.copy_(torch.from_numpy(out))
         n_commit.copy_(torch.from_numpy(nc))
 
-    for f in (lm_head_verify, pack_predictor, predictor_stop, draft_sample, residual_sample, commit_step):
+    def lambda_sweep(self, p_hist, costs, lams):
+        return torch.from_numpy(O.lambda_sweep(p_hist.numpy(), costs.numpy(), lams.numpy())[0])
+
+    for f in (lm_head_verify, pack_predictor, predictor_stop, draft_sample, residual_sample, commit_step, lambda_sweep):
         setattr(OracleOps, f.__name__, f)
 
 

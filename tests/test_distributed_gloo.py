@@ -1,6 +1,7 @@
 """The N > 1 exchange logic of asd_amd.distributed on CPU: world_size 2, gloo, 127.0.0.1, with the
 oracle as `ops` (tests/oracle_backend.py: OracleOps).  Checks that the sharded forms give the
-single-process oracle answer and that only the small messages cross ranks."""
+single-process oracle answer and that only the small messages cross ranks.  The multi-rank token-level LOOP
+(draft / 32B / 72B roles, stop-or-escalate) is covered by tests/test_hierarchy.py."""
 import os
 import socket
 import sys
@@ -84,44 +85,12 @@ def _worker(rank, world, port, what, ret):
                 assert torch.equal(t2, tok) and torch.equal(l2, lp_d)
                 lp, acc, n_acc, bits = OracleOps().verify_accept(lg, t2, l2, u)
                 link.send_verdict(acc, n_acc)
-        elif what == "tier_loop":
-            # BASELINE configs[3] in miniature: draft tier on rank 0, target tier on rank 1, tiny models
-            from asd_amd.serving.synthetic_lm import SyntheticLM, tiny
-            from asd_amd.serving.tiered import run_draft_tier, run_target_tier
-            torch.manual_seed(0)
-            prompt = torch.randint(0, 1000, (3, 6))
-            link = D.TierLink(draft_rank=0, target_rank=1)
-            base = SyntheticLM(tiny(), dtype=torch.float32, device="cpu", seed=1, logit_scale=2.0)
-            if rank == 0:
-                tr = run_draft_tier(base, link, prompt, 20, draft_len=4, seed=11)
-            else:
-                tgt = SyntheticLM(tiny(), dtype=torch.float32, device="cpu", seed=1, logit_scale=2.0)
-                with torch.no_grad():
-                    tgt.lm_head.weight.add_(torch.randn_like(tgt.lm_head.weight) * 0.02)
-                tr = run_target_tier(tgt, link, prompt, 20, draft_len=4, ops=OracleOps(), seed=22)
-            assert tr.tokens.shape == (3, 20) and tr.steps >= 4
-            assert int(tr.tokens.min()) >= 0 and int(tr.tokens.max()) < 1000
-            # both tiers must hold the same committed stream and the same verdicts
-            mine = torch.cat([tr.tokens.reshape(-1).to(torch.int64), torch.tensor([tr.steps, tr.verified_tokens])])
-            other = torch.empty_like(mine)
-            if rank == 0:
-                dist.send(mine, dst=1)
-                dist.recv(other, src=1)
-            else:
-                dist.recv(other, src=0)
-                dist.send(mine, dst=0)
-            assert torch.equal(mine, other)
-            accepted = sum(int(m.sum()) for m in tr.accept_masks)
-            assert accepted > 0
-            if rank == 0:                               # the link never carried a [B,K,V] tensor
-                per_step = tr.bytes_draft_to_target / tr.steps
-                assert per_step <= 8 * 3 * 4 + 3 * 1000 * 4
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("what", ["vocab", "vocab_hidden", "batch", "tiers", "tier_loop"])
+@pytest.mark.parametrize("what", ["vocab", "vocab_hidden", "batch", "tiers"])
 def test_two_rank_gloo(what):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
