@@ -25,7 +25,8 @@ COMMON = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=
           "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", f"-I{INC}", f"-I{CSRC}"]
 SOURCES = {
     "api.hip": [],
-    "verify_accept.hip": ["-ffp-contract=off"],   # hosts the in-kernel epilogue (predictor_device.hpp)
+    # hosts the in-kernel epilogue (predictor_device.hpp); the streaming prologue's arguments are preloaded into SGPRs
+    "verify_accept.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=11"],
     "residual_sample.hip": [],
     "commit.hip": [],
     "lm_head_verify.hip": ["-ffp-contract=off"],  # ends in the same finish_row arithmetic as verify_accept.hip

@@ -107,6 +107,12 @@ struct Elem<ASD_DTYPE_BF16> {
     static __device__ __forceinline__ float scalar(const void* p, int64_t i) {
         return __uint_as_float(static_cast<uint32_t>(static_cast<const uint16_t*>(p)[i]) << 16);
     }
+    // the load and its first use split apart: raw() issues the load, from_raw() converts where the value is needed
+    // (the s_waitcnt lands at the first USE; a volatile load would be followed by a full vmcnt(0) on this target)
+    static __device__ __forceinline__ uint32_t raw(const void* p, int64_t i) {
+        return static_cast<const uint16_t*>(p)[i];
+    }
+    static __device__ __forceinline__ float from_raw(uint32_t r) { return __uint_as_float(r << 16); }
     static __device__ __forceinline__ void accum(const u32x4& v, float c2, float& m2, float& s) {
         float x[8];
 #pragma unroll
@@ -125,6 +131,12 @@ struct Elem<ASD_DTYPE_F16> {
     static constexpr uint32_t kNegInfWord = 0xFC00FC00u;
     static __device__ __forceinline__ float scalar(const void* p, int64_t i) {
         return static_cast<float>(static_cast<const _Float16*>(p)[i]);
+    }
+    static __device__ __forceinline__ uint32_t raw(const void* p, int64_t i) {
+        return static_cast<const uint16_t*>(p)[i];
+    }
+    static __device__ __forceinline__ float from_raw(uint32_t r) {
+        return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(r)));
     }
     static __device__ __forceinline__ void accum(const u32x4& v, float c2, float& m2, float& s) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -148,6 +160,10 @@ struct Elem<ASD_DTYPE_F32> {
     static __device__ __forceinline__ float scalar(const void* p, int64_t i) {
         return static_cast<const float*>(p)[i];
     }
+    static __device__ __forceinline__ uint32_t raw(const void* p, int64_t i) {
+        return static_cast<const uint32_t*>(p)[i];
+    }
+    static __device__ __forceinline__ float from_raw(uint32_t r) { return __uint_as_float(r); }
     static __device__ __forceinline__ void accum(const u32x4& v, float c2, float& m2, float& s) {
         float x[4];
 #pragma unroll

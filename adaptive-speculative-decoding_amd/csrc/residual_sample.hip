@@ -425,27 +425,50 @@ __global__ __launch_bounds__(kRsThreads) void k_ds_hist(const RsParams p, const 
         if (h[i]) atomicAdd(out + i, h[i]);
 }
 
-// one wave per row: scan the level's histogram from the top digit down
-__global__ __launch_bounds__(64) void k_ds_scan(const DsParams d, int first) {
-    __shared__ unsigned long long chunk[64];
+// one workgroup per row: scan the level's histogram from the top digit down.  The histogram is staged in LDS with
+// coalesced loads (and zeroed in global memory on the way: ready for the next level / the next call); thread t owns
+// the t-th chunk of digits counted from the TOP, an exclusive prefix over the threads (wave scan + one LDS hop) finds
+// the chunk in which the cumulative mass reaches the target, and its owner walks the chunk's digits.
+constexpr int kScanThreads = 256;
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_ds_scan(const DsParams d, int first) {
+    __shared__ unsigned long long h[kDsDigits];
+    __shared__ unsigned long long wave_tot[kScanThreads / 64];
     __shared__ unsigned long long sel_above;
     __shared__ int sel_digit;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int digits = 1 << d.bits;
-    const int per = digits / 64;                          // 64 (12-bit level) or 4 (8-bit level)
     unsigned long long* hist = d.hist + static_cast<int64_t>(b) * kDsDigits;
-    // lane 0 owns the TOP `per` digits
-    const int hi = digits - lane * per, lo = hi - per;
+    for (int i = t; i < digits; i += kScanThreads) {
+        h[i] = hist[i];
+        hist[i] = 0ull;
+    }
+    if (t == 0) sel_digit = -1;
+    __syncthreads();
+    const int per = digits >= kScanThreads ? digits / kScanThreads : 1;      // 16 (12-bit level) or 1 (8-bit level)
+    const int hi = digits - t * per, lo = hi - per;                           // thread 0 owns the TOP digits
     unsigned long long mine = 0ull;
-    for (int j = lo; j < hi; ++j) mine += hist[j];
-    chunk[lane] = mine;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lo >= 0)
+        for (int j = lo; j < hi; ++j) mine += h[j];
+    const unsigned long long incl = wave_incl_scan_u64(mine, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned long long base = 0ull, total = 0ull;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        if (w < wave) base += wave_tot[w];
+        total += wave_tot[w];
+    }
     DsState st = d.state[b];
     if (first) {
-        unsigned long long total = 0ull;
-        for (int l = 0; l < 64; ++l) total += chunk[l];
         unsigned long long tg = static_cast<unsigned long long>(static_cast<double>(d.top_p) * static_cast<double>(total));
         if (tg > total) tg = total;
         if (tg == 0ull) tg = 1ull;
@@ -454,32 +477,26 @@ __global__ __launch_bounds__(64) void k_ds_scan(const DsParams d, int first) {
         st.prefix = 0u;
         st.empty = total == 0ull ? 1u : 0u;
     }
-    unsigned long long before = st.above;
-    for (int l = 0; l < lane; ++l) before += chunk[l];
-    const bool holds = mine > 0ull && before < st.target && st.target <= before + mine;
-    const unsigned long long bal = __ballot(holds);
-    if (lane == 0) { sel_digit = -1; sel_above = st.above; }
-    __builtin_amdgcn_wave_barrier();
-    if (bal != 0ull && lane == __builtin_ctzll(bal)) {
+    const unsigned long long before = st.above + base + incl - mine;
+    if (mine > 0ull && before < st.target && st.target <= before + mine) {     // exactly one thread
         unsigned long long acc = before;
         int pick = lo;
         for (int j = hi - 1; j >= lo; --j) {
-            const unsigned long long m = hist[j];
+            const unsigned long long m = h[j];
             if (m > 0ull && acc + m >= st.target) { pick = j; break; }
             acc += m;
         }
         sel_digit = pick;
         sel_above = acc;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int j = lo; j < hi; ++j) hist[j] = 0ull;         // ready for the next level / the next call
-    if (lane == 0) {
+    __syncthreads();
+    if (t == 0) {
         const int dg = sel_digit;
         if (dg < 0) st.empty = 1u;                        // no digit reaches the target: nothing to truncate
-        else st.prefix |= static_cast<uint32_t>(dg) << d.shift;
-        st.above = sel_above;
+        else {
+            st.prefix |= static_cast<uint32_t>(dg) << d.shift;
+            st.above = sel_above;
+        }
         d.state[b] = st;
         if (d.last) d.thr[b] = st.empty ? -INFINITY : key_floor_value(st.prefix);
     }
@@ -568,7 +585,7 @@ int launch_ds(RsParams p, DsParams d, bool nucleus, bool wide_key, hipStream_t s
             d.bits = widths[lv];
             d.last = lv == levels - 1;
             hipLaunchKernelGGL(k_ds_hist<DT>, grid, block, 0, st, p, d);
-            hipLaunchKernelGGL(k_ds_scan, dim3(p.B), dim3(64), 0, st, d, lv == 0 ? 1 : 0);
+            hipLaunchKernelGGL(k_ds_scan, dim3(p.B), dim3(kScanThreads), 0, st, d, lv == 0 ? 1 : 0);
         }
         p.b_thr = d.thr;
     }

@@ -107,8 +107,13 @@ __device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, 
 // FUSED: compile-time variant that also carries the in-kernel epilogue (N1 second form).  It is a separate
 // instantiation on purpose: the epilogue's prefetch registers and code took the plain kernel from ~40 to 111
 // VGPRs and cost it 6 % (A/B in one process), so the plain kernel does not contain it at all.
+// The first eight arguments repeat the VerifyParams fields the streaming prologue needs (row base, extents, tok).
+// They are separate scalars ON PURPOSE: this file is compiled with -amdgpu-kernarg-preload-count, so the command
+// processor hands them to every wave in SGPRs at wave start and the first tile loads are issued without waiting for
+// any s_load of the kernarg segment (the by-value struct is fetched meanwhile and first used behind those loads).
 template <int DT, int THREADS, int UNROLL, bool NT, bool FUSED>
-__global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
+__global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const int32_t* a_tok, int64_t a_ld_row, int a_V,
+                                                    int a_K, int a_S, float a_scale2, int a_own, const VerifyParams p) {
     using E = Elem<DT>;
     constexpr int kWaves = THREADS / 64;
     __shared__ uint32_t next_tile;
@@ -122,33 +127,40 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int S = p.S;
-    const float c2 = p.scale2;
+    const int S = a_S;
+    const float c2 = a_scale2;
     const int64_t bid = blockIdx.x;
     const int row = static_cast<int>(bid / S);
     const int split = static_cast<int>(bid - static_cast<int64_t>(row) * S);
-    const int b = row / p.K;
-    const int k = row - b * p.K;
+    const int b = row / a_K;
+    const int k = row - b * a_K;
 
-    const char* rowp = static_cast<const char*>(p.logits) + static_cast<int64_t>(row) * p.ld_row * E::kBytes;
+    const char* rowp = static_cast<const char*>(a_logits) + static_cast<int64_t>(row) * a_ld_row * E::kBytes;
     const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(rowp) & 15u);
     int head = mis ? static_cast<int>((16u - mis) / E::kBytes) : 0;
-    if (head > p.V) head = p.V;
-    const int nvec = (p.V - head) / E::kPerVec;
-    const int tail = p.V - head - nvec * E::kPerVec;
+    if (head > a_V) head = a_V;
+    const int nvec = (a_V - head) / E::kPerVec;
+    const int tail = a_V - head - nvec * E::kPerVec;
     const char* body = rowp + static_cast<int64_t>(head) * E::kBytes;
     const int v0 = static_cast<int>(static_cast<int64_t>(nvec) * split / S);
     const int v1 = static_cast<int>(static_cast<int64_t>(nvec) * (split + 1) / S);
 
-    // the row's own scalars, fetched by lane 0 under the stream (one workgroup per row only)
-    const bool own_row = (S == 1) && (p.mode == 1 || p.K <= kFastMaxK);
+    // the row's own scalars, fetched by lane 0 under the stream (one workgroup per row only).  Every one of these
+    // small loads is ISSUED early and CONSUMED after the streaming loop (the compiler waits at the first use, and the
+    // loop's LDS atomics keep it from sinking the loads).  Nothing before the barrier below waits for memory: the
+    // earlier form converted the gathered logit on the spot, which put an `s_waitcnt vmcnt(0)` in front of the
+    // barrier -- wave 0 sat there until its first two tiles AND the gather (queued behind the whole CU's initial
+    // requests) had landed, and with it every wave of the workgroup (stamps: first tile consumed 4.2 us after the start).
+    const bool own_row = a_own != 0;   // launcher: (S == 1) && (mode == 1 || K <= kFastMaxK)
     float x_tok = -INFINITY, lpd = 0.0f, uu = 1.0f;
+    uint32_t raw_tok = 0, raw_lpd = 0, raw_u = 0x3f800000u, raw_x = 0;
+    bool have_x = false;
     double lu_row = 0.0;
-    int64_t t_tok = -1;
-    if (own_row && tid == 0) {
-        t_tok = static_cast<int64_t>(p.tok[row]) - p.v_offset;
-        if (p.mode == 0) { lpd = p.lp_d[row]; uu = p.u[row]; }
-    }
+    // vector loads (the index is laundered through a VGPR): a scalarised s_load would share lgkmcnt with the LDS
+    // traffic of the loop and stall wave 0 at its first tile claim
+    int vrow = row;
+    asm volatile("" : "+v"(vrow));
+    if (own_row && tid == 0) raw_tok = static_cast<uint32_t>(a_tok[vrow]);   // the oldest load of wave 0: waited for alone
 
     // ---- streaming: waves claim UNROLL-KiB tiles from an LDS counter ---------------------------
     // Static striding lets the oldest wave group run ahead (age-priority arbitration: measured
@@ -171,25 +183,31 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     for (int j = 0; j < UNROLL; ++j) ra[j] = load16<NT>(rsrc, ta * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) rb[j] = load16<NT>(rsrc, tb * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
-    if (own_row && tid == 0) {   // off the tail: the gather and log(u) run under the stream
-        if (t_tok >= 0 && t_tok < p.V) x_tok = E::scalar(rowp, t_tok);
-        if (p.mode == 0) lu_row = log_u(uu);
+    ASD_STAMP_AT(7);
+    __syncthreads();   // next_tile is visible; the first two tiles of every wave are already in flight
+
+    // behind the barrier, still ahead of the loop: the loads whose ADDRESS needs a loaded value (the drafted token's
+    // logit) and the <= 7-element unaligned head / ragged tail of the row -- issued, not waited for
+    asm volatile("" : "+v"(raw_tok));   // first use of the token id: here, not hoisted in front of the tile loads
+    const int64_t t_tok = static_cast<int64_t>(static_cast<int32_t>(raw_tok)) - p.v_offset;
+    if (own_row && tid == 0 && t_tok >= 0 && t_tok < a_V) {
+        raw_x = E::raw(rowp, t_tok);
+        have_x = true;
     }
+    if (own_row && tid == 0 && p.mode == 0) {   // (the by-value struct is first used behind the barrier)
+        raw_lpd = reinterpret_cast<const uint32_t*>(p.lp_d)[vrow];
+        raw_u = reinterpret_cast<const uint32_t*>(p.u)[vrow];
+    }
+    uint32_t raw_head = 0, raw_tail = 0;
+    const bool do_head = wave == 0 && split == 0 && lane < head;
+    const bool do_tail = wave == 0 && split == S - 1 && lane >= 32 && lane - 32 < tail;
+    if (do_head) raw_head = E::raw(rowp, lane);
+    if (do_tail) raw_tail = E::raw(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + (lane - 32));
     EpiPrefetch pre;
     const bool fused = FUSED && own_row && p.mode == 0;
     if (FUSED) {
         if (fused && wave == 0) epi_prefetch(p.epi, b, lane, pre);   // features + predictor weights, also under the stream
     }
-    if (wave == 0) {
-        // unaligned head / ragged tail (<= 7 elements each) of the first / last slice: slot n_tiles
-        float hm = kSentinel, hs = 0.0f;
-        if (split == 0 && lane < head) accum_scalar(E::scalar(rowp, lane), c2, hm, hs);
-        if (split == S - 1 && lane >= 32 && lane - 32 < tail)
-            accum_scalar(E::scalar(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + (lane - 32)), c2, hm, hs);
-        wave_merge(hm, hs);
-        if (lane == 0) stage[n_tiles] = (static_cast<uint64_t>(__float_as_uint(hs)) << 32) | __float_as_uint(hm);
-    }
-    __syncthreads();   // next_tile is visible; the first two tiles of every wave are already in flight
 
 #define ASD_CLAIM(dst)                                                                                   \
     do {                                                                                                 \
@@ -230,6 +248,26 @@ __global__ __launch_bounds__(THREADS) void k_verify(const VerifyParams p) {
     if (lane == 0 && g_asd_stamps)   // per-wave stream end, after the per-workgroup records
         g_asd_stamps[static_cast<size_t>(gridDim.x) * 8 + static_cast<size_t>(blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (wave == 0) {
+        // the small loads issued ahead of the loop are consumed here: head / tail elements -> slot n_tiles,
+        // the drafted token's logit and log(u) for lane 0
+        // pin the first use of the loaded values HERE: without it the compiler hoists the (cheap, speculatable)
+        // conversions up to the loads and waits for them in front of the loop
+        asm volatile("" : "+v"(raw_x), "+v"(raw_head), "+v"(raw_tail), "+v"(raw_lpd), "+v"(raw_u));
+        float hm = kSentinel, hs = 0.0f;
+        if (do_head) accum_scalar(E::from_raw(raw_head), c2, hm, hs);
+        if (do_tail) accum_scalar(E::from_raw(raw_tail), c2, hm, hs);
+        wave_merge(hm, hs);
+        if (lane == 0) stage[n_tiles] = (static_cast<uint64_t>(__float_as_uint(hs)) << 32) | __float_as_uint(hm);
+        if (own_row && tid == 0) {
+            if (have_x) x_tok = E::from_raw(raw_x);
+            if (p.mode == 0) {
+                lpd = __uint_as_float(raw_lpd);
+                uu = __uint_as_float(raw_u);
+                lu_row = log_u(uu);
+            }
+        }
+    }
     // tile slots -> slice: wave 0 folds slots lane, lane+64, ... in order, then across lanes
     __syncthreads();
     if (wave != 0) return;
@@ -388,15 +426,13 @@ struct Geometry {
     int splits, threads, unroll, nt;
 };
 
-// Launch geometry (numbers: profiles/r01_sweep_*.json, MI355X, 256 CUs, dynamic-tile kernel).
-//   rows >= CUs : one workgroup per row, no split.  1024 lanes x 2-KiB tiles when every CU gets exactly
-//                 one row-sized workgroup (B=32: 16.2 us), 512 lanes x 4-KiB tiles when rows queue up
-//                 behind each other (B=128: 49.1 us = 6.34 TB/s).
-//   rows <  CUs : split rows until ~one 512-lane workgroup per CU exists (B=8: S=4, 8.6 us); a slice is
+// Launch geometry (numbers: profiles/r02_sweep_*.json, MI355X, 256 CUs, dynamic-tile kernel, preloaded arguments).
+//   rows >= CUs : one workgroup per row, no split: 512 lanes x 4-KiB tiles (B=32: 15.3 us = 5.08 TB/s against 15.6 us
+//                 for 1024 lanes x 2-KiB tiles; B=128: 49.2 us = 6.33 TB/s).
+//   rows <  CUs : split rows until ~one 512-lane workgroup per CU exists (B=8: S=4, 8.4 us); a slice is
 //                 never cut below one tile per wave.
 Geometry choose_geometry(int R, int K, int V, int dtype, int cus) {
-    Geometry g{1, 1024, 2, 1};
-    if (R > cus) { g.threads = 512; g.unroll = 4; }
+    Geometry g{1, 512, 4, 1};
     if (R >= cus) return g;
     g.threads = 512;
     g.unroll = 2;
@@ -412,12 +448,16 @@ Geometry choose_geometry(int R, int K, int V, int dtype, int cus) {
     return g;
 }
 
+inline int own_row_of(const VerifyParams& p) { return (p.S == 1 && (p.mode == 1 || p.K <= kFastMaxK)) ? 1 : 0; }
+
 template <int DT, int THREADS, int UNROLL>
 void launch_nt(const VerifyParams& p, int64_t grid, hipStream_t st, int nt) {
     if (nt)
-        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, true, false>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st, p);
+        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, true, false>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st,
+                           p.logits, p.tok, p.ld_row, p.V, p.K, p.S, p.scale2, own_row_of(p), p);
     else
-        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, false, false>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st, p);
+        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, false, false>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st,
+                           p.logits, p.tok, p.ld_row, p.V, p.K, p.S, p.scale2, own_row_of(p), p);
 }
 
 template <int DT, int THREADS>
@@ -488,8 +528,10 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
         if (!big && !(g.threads == 512 && g.unroll == 4)) return ASD_ERR_UNSUPPORTED;
 #define ASD_LAUNCH_FUSED(DT)                                                                                      \
     do {                                                                                                          \
-        if (big) hipLaunchKernelGGL((k_verify<DT, 1024, 2, true, true>), gd, dim3(1024), 0, st, p);               \
-        else hipLaunchKernelGGL((k_verify<DT, 512, 4, true, true>), gd, dim3(512), 0, st, p);                     \
+        if (big) hipLaunchKernelGGL((k_verify<DT, 1024, 2, true, true>), gd, dim3(1024), 0, st, p.logits, p.tok, p.ld_row, \
+                                    p.V, p.K, p.S, p.scale2, own_row_of(p), p);                                   \
+        else hipLaunchKernelGGL((k_verify<DT, 512, 4, true, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row,  \
+                                p.V, p.K, p.S, p.scale2, own_row_of(p), p);                                       \
     } while (0)
         switch (dtype) {
             case ASD_DTYPE_BF16: ASD_LAUNCH_FUSED(ASD_DTYPE_BF16); break;

@@ -24,6 +24,7 @@ from bench import WORKLOADS, build_inputs  # noqa: E402
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
     geom = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 0, 0, -1]
+    chain = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     lib_path = os.path.join(out, "libasd_hip_stamp.so")
@@ -48,15 +49,24 @@ def main():
     opt = verify_options(1.0, *geom)
     st = torch.cuda.current_stream().cuda_stream
     res, xcc, waves = [], [], []
+    if chain > 1:
+        for j in range(600):   # settle clocks like bench.py does
+            bj = bufs[j % nbuf]
+            oj = bj['out']
+            fn(bj['logits'].data_ptr(), 1, V, bj['tok'].data_ptr(), bj['lp_d'].data_ptr(), bj['u'].data_ptr(), B, Kk, V, oj.lp_target.data_ptr(), oj.accept.data_ptr(), oj.n_acc.data_ptr(), oj.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes, C.addressof(opt), st)
     for it in range(12):
         buf = bufs[it % nbuf]
         o = buf["out"]
         stamps.zero_()
         torch.cuda.synchronize()
-        rc = fn(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(), buf["u"].data_ptr(), B, Kk,
-                V, o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(), o.accept_bits.data_ptr(),
-                ws.buf.data_ptr(), ws.bytes, C.addressof(opt), st)
-        assert rc == 0, rc
+        # steady state: `chain` back-to-back launches, the stamps that remain are the LAST launch's
+        for j in range(chain):
+            bj = bufs[(it + j) % nbuf]
+            oj = bj["out"]
+            rc = fn(bj["logits"].data_ptr(), 1, V, bj["tok"].data_ptr(), bj["lp_d"].data_ptr(), bj["u"].data_ptr(), B, Kk,
+                    V, oj.lp_target.data_ptr(), oj.accept.data_ptr(), oj.n_acc.data_ptr(), oj.accept_bits.data_ptr(),
+                    ws.buf.data_ptr(), ws.bytes, C.addressof(opt), st)
+            assert rc == 0, rc
         torch.cuda.synchronize()
         raw = stamps.cpu().numpy()
         grid = B * Kk * (geom[0] if geom[0] > 0 else 1)   # default geometry at rows >= CUs: one workgroup per row
@@ -65,14 +75,14 @@ def main():
         live = s[:, 0] > 0
         s = s[live].astype(np.float64)
         t0 = s[:, 0].min()
-        rel = (s[:, :6] - t0) / 100.0      # us
+        rel = (s[:, [0, 1, 2, 3, 4, 5, 7]] - t0) / 100.0      # us
         if it >= 2:
             res.append(rel)
             xcc.append(s[:, 6].astype(int))
             waves.append((wv - t0) / 100.0)
     rel = np.concatenate(res)
-    names = ["start", "first batch consumed", "stream end", "wg reduced", "before ticket", "done"]
-    print(f"workload {wl}, geometry {geom}, {len(res)} launches, {rel.shape[0] // len(res)} workgroups each; us from first start")
+    names = ["start", "first batch consumed", "stream end", "wg reduced", "before ticket", "done", "first loads issued"]
+    print(f"workload {wl}, geometry {geom}, chain {chain}, {len(res)} launches, {rel.shape[0] // len(res)} workgroups each; us from first start")
     for i, n in enumerate(names):
         col = rel[:, i]
         col = col[col >= 0]
@@ -83,7 +93,8 @@ def main():
     print(f"  stream phase (t2-t1)   p50 {np.median(per):7.2f}  max {per.max():7.2f}")
     print(f"  ramp (t1-t0)           p50 {np.median(rel[:, 1] - rel[:, 0]):7.2f}  max {(rel[:, 1] - rel[:, 0]).max():7.2f}")
     ok = rel[:, 5] > 0
-    print(f"  tail (t5-t2)           p50 {np.median((rel[:, 5] - rel[:, 2])[ok]):7.2f}  max {(rel[:, 5] - rel[:, 2])[ok].max():7.2f}")
+    if ok.any():
+        print(f"  tail (t5-t2)           p50 {np.median((rel[:, 5] - rel[:, 2])[ok]):7.2f}  max {(rel[:, 5] - rel[:, 2])[ok].max():7.2f}")
 
 
     w = np.concatenate(waves)
