@@ -266,6 +266,74 @@ def gen_logprob_idiom(rng):
              logprob=np.array(out32, np.float64))
 
 
+FULL_V = 152064          # Qwen2.5 vocabulary: the size the path actually runs at
+FULL_SEED = 20251004
+
+
+def full_size_row(seed: int, row: int) -> np.ndarray:
+    """The f32 score row of the full-size log-prob goldens: regenerated from (seed, row) on the GPU box by the test
+    (tests/test_gpu_verify.py) -- the fixture stores seeds and expected values, not 15 MB of scores."""
+    return (np.random.default_rng([seed, row]).standard_normal(FULL_V) * 4.0).astype(np.float32)
+
+
+def gen_logprob_idiom_full():
+    """generate_training_data.py:128-136 run with torch exactly as written, at V = 152064, on the scores the
+    reference's generate() call (:110-119: temperature=0.7, top_p=0.9) hands to that loop:
+
+      f32          raw f32 scores (no warpers): the idiom on a plain row
+      bf16 / f16   scores that went through 16-bit storage (the reference loads its models in fp16, :79-85; HF
+                   up-casts the model's logits to f32 before the warpers), divided by T = 0.7 (TemperatureLogitsWarper)
+      *_topp       ... and then masked to the top-p = 0.9 nucleus (TopPLogitsWarper: -inf outside); `keep` lists the
+                   surviving token ids so that the test can rebuild the masked row exactly
+
+    For every row: the token (inside the nucleus; one row per masked variant deliberately OUTSIDE -> -inf) and the
+    logprob `.item()` of the idiom.  HF's own warper classes are used (third party for the reference as well)."""
+    import torch.nn.functional as F
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopPLogitsWarper
+    temp, topp = TemperatureLogitsWarper(0.7), TopPLogitsWarper(0.9)
+    variants = ["f32", "bf16", "f16", "bf16_topp", "f16_topp"]
+    per = 6
+    rec = dict(variant=[], row=[], tok=[], logprob=[], keep_off=[0], keep=[])
+    rng = np.random.default_rng(FULL_SEED)
+    for vi, var in enumerate(variants):
+        for j in range(per):
+            row = vi * 100 + j
+            x = full_size_row(FULL_SEED, row)
+            if var.startswith("bf16"):
+                x = torch.from_numpy(x).to(torch.bfloat16).float().numpy()        # round to nearest even
+            elif var.startswith("f16"):
+                x = x.astype(np.float16).astype(np.float32)
+            score = torch.from_numpy(x.copy())[None, :]                 # outputs.scores[i]: [1, V]
+            keep = np.zeros(0, np.int32)
+            if var != "f32":
+                score = temp(None, score)
+            if var.endswith("_topp"):
+                score = topp(None, score)
+                keep = torch.isfinite(score[0]).nonzero()[:, 0].numpy().astype(np.int32)
+            if var.endswith("_topp") and j == per - 1:
+                tok = int(np.setdiff1d(np.arange(64), keep)[0])           # a token the warper masked: log(0)
+            elif var.endswith("_topp"):
+                tok = int(rng.choice(keep))
+            elif j % 2 == 0:
+                tok = int(np.argmax(x))
+            else:
+                tok = int(rng.integers(0, FULL_V))
+            probs = F.softmax(score[0], dim=-1)                           # :131
+            token_id = torch.tensor(tok)
+            lp = torch.log(probs[token_id]).item()                        # :133
+            rec["variant"].append(vi)
+            rec["row"].append(row)
+            rec["tok"].append(tok)
+            rec["logprob"].append(lp)
+            rec["keep"].append(keep)
+            rec["keep_off"].append(rec["keep_off"][-1] + keep.size)
+    np.savez(os.path.join(OUT, "logprob_idiom_full.npz"), seed=np.int64(FULL_SEED), vocab=np.int64(FULL_V),
+             variants=np.array(variants), variant=np.array(rec["variant"], np.int32), row=np.array(rec["row"], np.int32),
+             tok=np.array(rec["tok"], np.int32), logprob=np.array(rec["logprob"], np.float64),
+             keep=np.concatenate(rec["keep"]).astype(np.int32), keep_off=np.array(rec["keep_off"], np.int64),
+             temperature=np.float32(0.7), top_p=np.float32(0.9))
+
+
 def gen_a4(dp, rng):
     tab = dp.OptimalStoppingTable(lambda_values=[0.1, 1.0, 10.0], num_stages=4)
     grid = [[a, b, c, 1.0] for a in (0.2, 0.5, 0.8) for b in (0.3, 0.6, 0.9) for c in (0.4, 0.7)]
@@ -377,6 +445,7 @@ def main():
     gen_logprob_idiom(rng)
     gen_a4(dp, rng)
     gen_optimizer(dp, np.random.default_rng(4321))
+    gen_logprob_idiom_full()
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -100,3 +100,30 @@ def assert_verify_matches(got, ref, check_mask=True):
         assert np.array_equal(got["accept"], ref["accept"])
         assert np.array_equal(got["n_acc"], ref["n_acc"])
         assert np.array_equal(got["bits"], ref["bits"])
+
+
+# The reference's per-token idiom (softmax -> index -> log, torch CPU f32) at V = 152064 is itself 0.3e-5 .. 1.7e-5 away
+# from the exact (f64) log-prob: torch's f32 accumulation of 152064 exponentials.  An exact kernel therefore cannot sit
+# within 1e-5 of THAT number on full-vocabulary rows; it is held to 1e-5 of the f64 oracle and to this bound of the idiom.
+REF_F32_SUM_ERR = 2.5e-5
+
+
+# ---- full-size reference-idiom goldens (tests/golden/logprob_idiom_full.npz, oracle/gen_golden.py) ----------------
+def full_size_row(seed: int, row: int, vocab: int = 152064) -> np.ndarray:
+    """The f32 score row the generator drew for (seed, row): the fixture stores seeds, not 15 MB of scores."""
+    return (np.random.default_rng([seed, row]).standard_normal(vocab) * 4.0).astype(np.float32)
+
+
+def full_size_cases(g):
+    """Yield (variant, tok, expected logprob, x16 f32 values after 16-bit storage (or raw f32), keep ids or None)."""
+    seed, V = int(g["seed"]), int(g["vocab"])
+    names = [str(v) for v in g["variants"]]
+    for i in range(g["tok"].shape[0]):
+        var = names[int(g["variant"][i])]
+        x = full_size_row(seed, int(g["row"][i]), V)
+        if var.startswith("bf16"):
+            x = O.bf16_bits_to_f32(O.f32_to_bf16_bits(x))
+        elif var.startswith("f16"):
+            x = x.astype(np.float16).astype(np.float32)
+        keep = g["keep"][int(g["keep_off"][i]):int(g["keep_off"][i + 1])] if var.endswith("_topp") else None
+        yield var, int(g["tok"][i]), float(g["logprob"][i]), x, keep

@@ -426,3 +426,55 @@ def test_fuzz_shapes_strides_dtypes_geometries(K_):
                 assert np.array_equal(got["n_acc"], ref["n_acc"]) and np.array_equal(got["bits"], ref["bits"])
         except AssertionError as e:
             raise AssertionError(f"fuzz case {it}: B={B} K={K} V={V} ld={ld} dtype={dtype} inv_t={inv_t} geom={geom}") from e
+
+
+def test_reference_idiom_goldens_at_full_vocabulary(golden):
+    """A6 pinned where the path runs (V = 152064): asd_verify_accept_ex against what the reference's own loop
+    (generate_training_data.py:128-136, executed by oracle/gen_golden.py in the dev container) returns for scores
+    that went through bf16 / fp16 storage, were divided by T = 0.7 and masked to the top-p = 0.9 nucleus by HF's
+    warpers (:110-119).  Inputs are regenerated from the fixture's seeds.  Two forms per 16-bit row: the raw stored
+    logits with the temperature folded into the pass, and the processed f32 row as the reference loop saw it."""
+    import torch
+    from asd_amd import kernels as K
+    from tests.helpers import LP_RTOL, REF_F32_SUM_ERR, encode_logits, full_size_cases, to_device_logits
+    g = golden.npz("logprob_idiom_full.npz")
+    T = np.float32(g["temperature"])
+    inv_t = float(np.float32(1.0) / T)
+    groups = {}
+    for var, tok, want, x, keep in full_size_cases(g):
+        V = x.size
+        if var == "f32":
+            groups.setdefault(("f32", O.DT_F32, 1.0), []).append((x, tok, want))
+            continue
+        dt = O.DT_BF16 if var.startswith("bf16") else O.DT_F16
+        xs = x.copy()
+        if keep is not None:
+            mask = np.ones(V, bool)
+            mask[keep] = False
+            xs[mask] = -np.inf
+        groups.setdefault((var + " stored, T in-kernel", dt, inv_t), []).append((xs, tok, want))
+        groups.setdefault((var + " processed f32 row", O.DT_F32, 1.0), []).append(((xs / T).astype(np.float32), tok, want))
+    checked = 0
+    for (name, dt, it), rows in groups.items():
+        n = len(rows)
+        store = np.stack([encode_logits(r[0], dt) for r in rows])
+        lg = to_device_logits(store, dt).view(n, 1, V)
+        tok = torch.tensor([[r[1]] for r in rows], dtype=torch.int32, device="cuda")
+        ws = K.VerifyWorkspace(n, 1, V, lg.dtype)
+        res = K.verify_accept(lg, tok, torch.zeros((n, 1), device="cuda"), torch.full((n, 1), 0.5, device="cuda"), ws,
+                              inv_temperature=it)
+        torch.cuda.synchronize()
+        got = res.lp_target.cpu().numpy()[:, 0].astype(np.float64)
+        want = np.array([r[2] for r in rows])
+        fin = np.isfinite(want)
+        # (1) against the exact value: the f64 oracle on the same stored row, BASELINE's 1e-5
+        exact = O.verify_accept(store, dt, tok.cpu().numpy(), np.zeros(n, np.float32), np.full(n, 0.5, np.float32), n, 1, V,
+                                inv_temperature=np.float32(it))["lp_t64"][:, 0]
+        np.testing.assert_allclose(got[fin], exact[fin], rtol=LP_RTOL, atol=LP_ATOL, err_msg=name)
+        # (2) against the reference's own f32 idiom: its softmax sum carries up to ~1.7e-5 of f32 accumulation error
+        # on full-vocabulary rows (helpers.REF_F32_SUM_ERR); on nucleus rows it is exact and so must the kernel be
+        tol = 2e-6 if "_topp" in name else REF_F32_SUM_ERR
+        np.testing.assert_allclose(got[fin], want[fin], rtol=LP_RTOL, atol=tol, err_msg=name)
+        assert np.isneginf(got[~fin]).all(), name
+        checked += n
+    assert checked == 6 + 4 * 12

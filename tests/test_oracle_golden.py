@@ -162,3 +162,43 @@ def test_lambda_sweep_oracle_matches_reference(golden):
     assert cost.tobytes() == g["cost"].tobytes() and ok.tobytes() == g["p_ok"].tobytes()
     total = cost + g["lam"][:, None] * (1 - ok)                     # compute_expected_cost, dp_solver.py:95-101
     assert total.tobytes() == g["expected_cost"].tobytes()
+
+
+def test_logprob_idiom_at_full_vocabulary_with_temperature_and_top_p(golden):
+    """A6 where the path actually runs: V = 152064, scores that went through bf16 / fp16 storage, divided by
+    T = 0.7 and masked to the top-p nucleus by HF's own warpers (generate_training_data.py:110-119), then the
+    reference idiom (:128-136) executed as written by oracle/gen_golden.py.  The oracle (f64 LSE) must agree to
+    1e-5 whether the temperature is folded into the pass (inv_temperature) or the processed row is given."""
+    from tests.helpers import REF_F32_SUM_ERR, encode_logits, full_size_cases
+    g = golden.npz("logprob_idiom_full.npz")
+    inv_t = np.float32(1.0) / np.float32(g["temperature"])
+    n = 0
+    worst = {False: 0.0, True: 0.0}
+    for var, tok, want, x, keep in full_size_cases(g):
+        V = x.size
+        one = lambda store, dt, it: O.verify_accept(store.reshape(1, V), dt, [tok], [0.0], [0.5], 1, 1, V,  # noqa: E731
+                                                    inv_temperature=it)["lp_t64"][0, 0]
+        if var == "f32":
+            got = [one(x, O.DT_F32, 1.0)]
+        else:
+            dt = O.DT_BF16 if var.startswith("bf16") else O.DT_F16
+            xs = x.copy()
+            if keep is not None:
+                mask = np.ones(V, bool)
+                mask[keep] = False
+                xs[mask] = -np.inf
+            processed = (xs / np.float32(g["temperature"])).astype(np.float32)       # the row the reference loop saw
+            got = [one(encode_logits(xs, dt), dt, inv_t), one(processed, O.DT_F32, 1.0)]
+        for v in got:
+            if np.isneginf(want):
+                assert np.isneginf(v)
+            else:
+                # the reference idiom is f32 end to end: at V = 152064 its own softmax sum is 0.3e-5 .. 1.7e-5 below the
+                # exact value (measured here against f64: the bias is torch's f32 accumulation, it vanishes on the
+                # top-p rows, which have tens of terms) -- so the f64 oracle is held to REF_F32_SUM_ERR, not to 1e-5
+                assert abs(v - want) <= REF_F32_SUM_ERR + 1e-6 * abs(want), (var, tok, v, want)
+                worst[var.endswith("_topp")] = max(worst[var.endswith("_topp")], abs(v - want))
+        assert abs(got[0] - got[-1]) <= 2e-6 or np.isneginf(want)     # folded temperature == processed row
+        n += 1
+    assert n == 30
+    assert worst[True] <= 1e-6, worst         # nucleus rows: the idiom is exact to f32 rounding
