@@ -193,7 +193,7 @@ static __device__ __forceinline__ double log2_split(float x) {
 // exact exponent and a v_log_f32 of the mantissa, which keeps their absolute error ~1e-7 without
 // a software f64 log on the kernel's tail.
 static __device__ __forceinline__ double log_u(float u) {
-    return kLn2d * log2_split(u);  // u == 0 -> -inf (accepts), u < 0 -> NaN (rejects)
+    return kLn2d * log2_split(u);  // u == 0 -> -inf (accepts any token of non-zero target probability), u < 0 -> NaN (rejects)
 }
 static __device__ __forceinline__ bool finish_row(float m2, float s, float x_tok, float c2, float lp_d, double lu,
                                                   float& lp_out) {
@@ -202,7 +202,9 @@ static __device__ __forceinline__ bool finish_row(float m2, float s, float x_tok
     const double l2 = static_cast<double>(m2) + log2_split(s);
     const double lp = kLn2d * (static_cast<double>(x_tok) * static_cast<double>(c2) - l2);
     lp_out = static_cast<float>(lp);
-    return lu <= lp - static_cast<double>(lp_d);
+    // p_t(tok) == 0 (a -inf target logit: top-p / top-k masked rows, an id outside the shard) never accepts, not
+    // even at u == 0 where log u = -inf <= -inf would: the rule is u < p_t / p_d.  NaN rejects by comparison.
+    return lp > -INFINITY && lu <= lp - static_cast<double>(lp_d);
 }
 
 static __device__ __forceinline__ void finish_sequence(bool flag, int lane, int K, int b, int32_t* n_acc,

@@ -14,8 +14,12 @@ What the reference's loop does per request (pipeline.py:165-286), and what this 
                      k*  = optimal_stopping_rule(p[:i+1], C[:i+1], lambda)            :251-256
                      stop when k* == i, else prompt_{i+1} = prompt + " " + output     :259-266
 
-`batch_process` really batches (the reference leaves it as a TODO, :331-338): all still-active
-requests of a stage go through ONE stage.generate call, ONE Bayes launch and ONE DP launch.
+`batch_process` really batches (the reference leaves it as a TODO, :331-338: "intelligent batching based on
+predicted stages"): the predictor is asked for every request's acceptance probability at every stage from the
+PROMPT alone, ONE DP launch over [n, L] turns that into a predicted stop stage, requests are grouped by it and the
+groups run shallowest first (a group's requests leave the cascade together, so the stage calls of a group stay
+full and easy requests are not held back by hard ones).  Inside a group all still-active requests of a stage go
+through ONE stage.generate call, ONE Bayes launch and ONE DP launch.  `batch_grouping="none"` keeps one group.
 
 stop_rule:
   "prefix" -- the reference's rule verbatim.  Because the DP is run on the prefix p[:i+1], and a
@@ -60,6 +64,7 @@ class PipelineConfig:
     stop_rule: str = "full"                                 # "full" | "prefix" (see module docstring)
     stage_names: Sequence[str] = DEFAULT_STAGE_NAMES
     stage_priors: Optional[Sequence[float]] = None          # prior p for not-yet-run stages ("full")
+    batch_grouping: str = "predicted_stage"                 # batch_process: "predicted_stage" | "none"
 
     @classmethod
     def from_yaml(cls, path: str) -> "PipelineConfig":
@@ -83,6 +88,8 @@ class PipelineConfig:
             kw["stage_names"] = tuple(sec["stage_names"])
         if "stage_priors" in sec:
             kw["stage_priors"] = tuple(float(x) for x in sec["stage_priors"])
+        if "batch_grouping" in sec:
+            kw["batch_grouping"] = str(sec["batch_grouping"])
         return cls(**kw)
 
 
@@ -97,6 +104,10 @@ class RequestResult:
     cache_hits: int
     total_tokens: int
     tokens_per_second: float
+    # --- build extensions (trailing, defaulted: the reference's positional construction still works) ---
+    stages_run: int = 0                                     # stages actually executed (>= stopped_at_stage + 1)
+    executed_costs: List[float] = field(default_factory=list)   # cost_per_token of every executed stage
+    predicted_stage: int = -1                               # batch_process grouping key (-1: not predicted)
 
 
 @dataclass
@@ -112,6 +123,7 @@ class _Active:
     cache_hits: int = 0
     total_tokens: int = 0
     k_star: int = -1
+    predicted_stage: int = -1
 
 
 def _fresh_stats(n_stages: int) -> Dict[str, Any]:
@@ -136,6 +148,8 @@ class AdaptiveSpeculativePipeline:
         self.active_requests: Dict[str, Dict[str, Any]] = {}
         if config.stop_rule not in ("full", "prefix"):
             raise ValueError("stop_rule must be 'full' or 'prefix'")
+        if config.batch_grouping not in ("predicted_stage", "none"):
+            raise ValueError("batch_grouping must be 'predicted_stage' or 'none'")
         logger.info("AdaptiveSpeculativePipeline initialized")
 
     # ------------------------------------------------------------------ public API
@@ -150,7 +164,39 @@ class AdaptiveSpeculativePipeline:
                                           request_id)
 
     def batch_process(self, prompts: List[str], max_tokens: int = 512, temperature: float = 0.7) -> List[RequestResult]:
-        return self._run_batch(list(prompts), max_tokens, temperature, [None] * len(prompts))
+        prompts = list(prompts)
+        if self.config.batch_grouping != "predicted_stage" or len(prompts) < 2 or self.config.stop_rule == "prefix":
+            return self._run_batch(prompts, max_tokens, temperature, [None] * len(prompts))
+        pred = self.predict_stop_stages(prompts)
+        results: List[Optional[RequestResult]] = [None] * len(prompts)
+        for stage in sorted(set(pred.tolist())):                       # shallowest group first
+            idx = [i for i, s in enumerate(pred) if s == stage]
+            out = self._run_batch([prompts[i] for i in idx], max_tokens, temperature, [None] * len(idx),
+                                  predicted=[int(stage)] * len(idx))
+            for i, r in zip(idx, out):
+                results[i] = r
+        return results  # type: ignore[return-value]
+
+    def predict_stop_stages(self, prompts: Sequence[str]) -> np.ndarray:
+        """The grouping key of batch_process: the stage the DP rule would stop at if every stage's acceptance
+        probability were what the predictor says from the prompt alone (no output, no log-probs yet).  One Bayes
+        launch and ONE DP launch for all n requests x L stages."""
+        cfg = self.config
+        names = list(cfg.stage_names)
+        L = len(names)
+        P = np.ones((len(prompts), L), dtype=np.float64)
+        for j, prompt in enumerate(prompts):
+            for i in range(L - 1):
+                P[j, i] = float(self.predictor.predict(prompt=prompt, draft_output="", draft_logprobs=None, stage_id=i,
+                                                       feature_extractor=self.feature_extractor))
+        backend = get_backend()
+        if cfg.risk_adjustment:
+            with self._stats_lock:
+                n_obs = max(100, self.stats["total_requests"])
+            P[:, :L - 1] = backend.bayes_adjust(P[:, :L - 1].reshape(-1), n_obs, cfg.risk_alpha, cfg.risk_beta).reshape(-1, L - 1)
+        costs = np.array([float(self.stage_manager.get_stage(n).cost_per_token) for n in names])
+        k_star, _ = backend.optimal_stopping(P, costs, cfg.lambda_value, False, 1.0, 1.0)
+        return np.asarray(k_star, dtype=np.int64)
 
     def update_lambda(self, new_lambda: float):
         old = self.config.lambda_value
@@ -195,10 +241,13 @@ class AdaptiveSpeculativePipeline:
 
     # ------------------------------------------------------------------ the stage loop, batched
     def _run_batch(self, prompts: List[str], max_tokens: int, temperature: float,
-                   request_ids: List[Optional[str]]) -> List[RequestResult]:
+                   request_ids: List[Optional[str]], predicted: Optional[List[int]] = None) -> List[RequestResult]:
         now = time.time()
         reqs = [_Active(request_id=rid or str(uuid.uuid4()), prompt=p, current_prompt=p, start_time=now)
                 for p, rid in zip(prompts, request_ids)]
+        if predicted is not None:
+            for r, s in zip(reqs, predicted):
+                r.predicted_stage = s
         for r in reqs:
             self.active_requests[r.request_id] = {"start_time": r.start_time,
                                                   "prompt": r.prompt[:100] + "..." if len(r.prompt) > 100 else r.prompt}
@@ -238,9 +287,10 @@ class AdaptiveSpeculativePipeline:
             todo, cached = [], {}
             for r in active:
                 hit = self.cache_manager.get_cache(r.request_id, i) if self.cache_manager else None
+                if hit:
+                    r.cache_hits += 1                                              # any cached entry counts (pipeline.py:192-194)
                 if hit and hit.get("output"):
                     cached[r.request_id] = hit["output"]
-                    r.cache_hits += 1
                 else:
                     todo.append(r)
             gen_out: Dict[str, Any] = {}
@@ -266,7 +316,8 @@ class AdaptiveSpeculativePipeline:
                     probs[j] = self._predict(r, i, text, lp if len(lp) else None)
             # ... then ONE Bayes launch and ONE DP launch for the whole batch
             if not last_stage and cfg.risk_adjustment:
-                n_obs = max(100, self.stats["total_requests"])                     # pipeline.py:235
+                with self._stats_lock:
+                    n_obs = max(100, self.stats["total_requests"])                 # pipeline.py:235
                 probs = backend.bayes_adjust(probs, n_obs, cfg.risk_alpha, cfg.risk_beta)
             for j, r in enumerate(active):
                 r.probabilities.append(float(probs[j]))
@@ -303,7 +354,8 @@ class AdaptiveSpeculativePipeline:
             self.cache_manager.truncate_at_stage(r.request_id, k)
         return RequestResult(request_id=r.request_id, output=r.outputs[k], stopped_at_stage=k, latency_ms=total_ms,
                              stage_probabilities=r.probabilities, stage_costs=r.costs[:k + 1],
-                             cache_hits=r.cache_hits, total_tokens=r.total_tokens, tokens_per_second=tps)
+                             cache_hits=r.cache_hits, total_tokens=r.total_tokens, tokens_per_second=tps,
+                             stages_run=len(r.outputs), executed_costs=list(r.costs), predicted_stage=r.predicted_stage)
 
     def _update_stats(self, result: RequestResult):
         a = 0.01                                                                   # pipeline.py:295

@@ -334,6 +334,42 @@ def gen_logprob_idiom_full():
              temperature=np.float32(0.7), top_p=np.float32(0.9))
 
 
+def gen_dynamic_lambda():
+    """DynamicCostOptimizer._optimize_lambda_parameter (src/serving/dynamic_cost_optimizer.py:425-487) called unbound
+    on a stand-in `self` (the class constructor would start its background thread); the reference source runs
+    unmodified.  Inputs cover every branch and its boundaries."""
+    from types import SimpleNamespace
+    mod = _load("ref_dynamic_cost_optimizer", os.path.join(SRC, "serving", "dynamic_cost_optimizer.py"))
+    fn = mod.DynamicCostOptimizer._optimize_lambda_parameter
+    rng = np.random.default_rng(777)
+    cases = []
+    lat_grid = [0.0, 100.0, 139.9, 140.0, 200.0, 260.0, 260.1, 900.0]
+    q_grid = [0.0, 0.5, 0.8499, 0.85, 0.9, 0.95, 0.951, 1.0]
+    c_grid = [0.0, 1.0, 1.19, 1.2, 1.4, 1.6, 1.61, 3.0]
+    for i in range(240):
+        if i < 64:
+            m = dict(avg_latency=lat_grid[i % 8], avg_quality=q_grid[(i // 8) % 8], avg_cost=c_grid[(i * 3) % 8])
+        else:
+            m = dict(avg_latency=float(rng.uniform(0, 600)), avg_quality=float(rng.uniform(0.5, 1.0)),
+                     avg_cost=float(rng.uniform(0.8, 2.2)))
+        if i % 17 == 0:
+            m.pop("avg_quality")
+        lam = float(rng.choice([0.1, 0.12, 1.0, 2.5, 9.95, 10.0]))
+        util = [float(x) for x in rng.uniform(0.6, 1.0, 4)]
+        if i % 5 == 0:
+            util = [0.95, 0.97, 0.99, 0.92]
+        rate = float(rng.uniform(0, 50))
+        forecast = [float(x) for x in rng.uniform(0, 60, 2)]
+        self_ = SimpleNamespace(lambda_adjustment=lam, target_latency=200, min_quality=0.85,
+                                load_predictor=SimpleNamespace(get_load_forecast=lambda hours_ahead=2, f=forecast: dict(enumerate(f))))
+        state = SimpleNamespace(gpu_utilization=dict(enumerate(util)), request_rate=rate)
+        out = float(fn(self_, m, state))
+        cases.append(dict(current_lambda=lam, metrics=m, gpu_utilization=util, request_rate=rate, load_forecast=forecast,
+                          new_lambda=out))
+    with open(os.path.join(OUT, "dynamic_lambda.json"), "w") as f:
+        json.dump(cases, f)
+
+
 def gen_a4(dp, rng):
     tab = dp.OptimalStoppingTable(lambda_values=[0.1, 1.0, 10.0], num_stages=4)
     grid = [[a, b, c, 1.0] for a in (0.2, 0.5, 0.8) for b in (0.3, 0.6, 0.9) for c in (0.4, 0.7)]
@@ -446,6 +482,7 @@ def main():
     gen_a4(dp, rng)
     gen_optimizer(dp, np.random.default_rng(4321))
     gen_logprob_idiom_full()
+    gen_dynamic_lambda()
     print("wrote", sorted(os.listdir(OUT)))
 
 

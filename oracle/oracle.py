@@ -197,7 +197,7 @@ def py_verify_accept(logits_f32: np.ndarray, tok, lp_d, u):
         lp = g - lse
         uu = np.asarray(u, dtype=np.float32).reshape(B, K).astype(np.float64)
         lu = np.where(uu > 0, np.log(np.where(uu > 0, uu, 1.0)), np.where(uu == 0, -np.inf, np.nan))
-        acc = lu <= (lp - np.asarray(lp_d, dtype=np.float32).reshape(B, K).astype(np.float64))
+        acc = (lp > -np.inf) & (lu <= (lp - np.asarray(lp_d, dtype=np.float32).reshape(B, K).astype(np.float64)))
     n_acc = np.array([int(np.argmin(np.append(a, False))) for a in acc], dtype=np.int32)
     return lp, acc.astype(np.uint8), n_acc
 

@@ -109,7 +109,7 @@ class OracleOps:
             lp = g - lse
             uu = u.numpy().astype(np.float64)
             lu = np.where(uu > 0, np.log(np.where(uu > 0, uu, 1.0)), -np.inf)
-            acc = (lu <= lp - lp_d.numpy().astype(np.float64)).astype(np.uint8)
+            acc = ((lp > -np.inf) & (lu <= lp - lp_d.numpy().astype(np.float64))).astype(np.uint8)
         n_acc = np.array([int(np.argmin(np.append(a, 0))) for a in acc], dtype=np.int32)
         bits = np.array([sum(int(a[k]) << k for k in range(K)) for a in acc], dtype=np.int64)
         return torch.from_numpy(lp.astype(np.float32)), torch.from_numpy(acc), torch.from_numpy(n_acc), torch.from_numpy(bits)

@@ -128,6 +128,9 @@ def test_edge_cases_follow_the_oracle():
     u = rng.uniform(0.05, 1, (B, K)).astype(np.float32)
     u[0, 0] = 0.0
     u[3, 1] = 0.0
+    u[1, 0] = 0.0                       # row 6: drafted token inside the -inf mask? (set below) -> rejected at u = 0
+    tok[1, 0] = 150                     # x[6, :] is unmasked; make row 6's token sit on a -inf logit instead:
+    x[6, 150] = -np.inf
     for dtype in (O.DT_F32, O.DT_BF16, O.DT_F16):
         from tests.helpers import encode_logits
         store = encode_logits(x, dtype)
@@ -139,7 +142,12 @@ def test_edge_cases_follow_the_oracle():
             ok = ~(ref["margin"] < 1e-4)
             assert_verify_matches(got, ref, check_mask=False)
             assert np.array_equal(got["accept"][ok], ref["accept"][ok])
-        assert got["accept"].reshape(-1)[0] == 1 and np.isneginf(got["lp_t"].reshape(-1)[0])  # u=0 accepts
+        # u = 0 with a token of ZERO target probability (id outside the vocabulary -> lp_t = -inf): rejected -- the rule
+        # is u < p_t / p_d, and log u = -inf <= -inf must not accept (torch.rand draws from [0, 1))
+        assert got["accept"].reshape(-1)[0] == 0 and np.isneginf(got["lp_t"].reshape(-1)[0])
+        # u = 0 with a token of non-zero target probability: always accepted
+        assert got["accept"][3, 1] == 1 and np.isfinite(got["lp_t"][3, 1])
+        assert got["accept"][1, 0] == 0 and np.isneginf(got["lp_t"][1, 0])      # -inf target logit, u = 0
         assert np.isnan(got["lp_t"].reshape(-1)[2]) and got["accept"].reshape(-1)[2] == 0
         assert np.isnan(got["lp_t"].reshape(-1)[4]) and got["accept"].reshape(-1)[4] == 0
 

@@ -253,7 +253,7 @@ def test_prefix_rule_reproduces_reference_trace():
 
 
 def test_full_rule_follows_the_dp_over_all_stages():
-    pipe, sm = _pipeline("full", lam=30.0, risk_adjustment=False)
+    pipe, sm = _pipeline("full", lam=30.0, risk_adjustment=False, batch_grouping="none")
     res = pipe.batch_process(["easy one", "hard one", "mid one", "hard two"])
     costs = [1.0, 1.6, 4.2, 8.8]
     for r, word in zip(res, ("easy", "hard", "mid", "hard")):
@@ -270,6 +270,7 @@ def test_full_rule_follows_the_dp_over_all_stages():
         assert r.stopped_at_stage == stop
         assert r.stage_probabilities == probs and r.stage_costs == costs[:stop + 1]
         assert r.total_tokens > 0 and r.latency_ms >= 0
+        assert r.stages_run == len(probs) >= stop + 1 and r.executed_costs == costs[:len(probs)]
     # batching: one generate() call per stage, shrinking as requests stop
     assert [len(c) for c in sm.stages["8b"].calls] == [4]
     assert all(len(c) <= 4 for c in sm.stages["13b"].calls) and len(sm.stages["13b"].calls) <= 1
@@ -287,6 +288,53 @@ def test_full_rule_follows_the_dp_over_all_stages():
     assert pipe.get_stats()["total_requests"] == 3
     r = asyncio.run(pipe.process_request_async("easy async", request_id="abc"))
     assert r.request_id == "abc"
+    pipe.shutdown()
+
+
+def test_batch_process_groups_requests_by_predicted_stop_stage():
+    """The reference's TODO (pipeline.py:331-338): requests are grouped by the stage ONE DP launch predicts from
+    the prompt-only scores, shallow groups run first; per request the result is what the ungrouped batch gives."""
+    prompts = ["easy a", "hard a", "mid a", "hard b", "easy b", "mid b", "hard c"]
+    plain, _ = _pipeline("full", lam=30.0, risk_adjustment=False, batch_grouping="none")
+    want = plain.batch_process(prompts)
+    pipe, sm = _pipeline("full", lam=30.0, risk_adjustment=False)
+    pred = pipe.predict_stop_stages(prompts)
+    costs = [1.0, 1.6, 4.2, 8.8]
+    for word, k in zip((p.split()[0] for p in prompts), pred):
+        base = {"easy": 0.97, "mid": 0.6, "hard": 0.05}[word]
+        P = [min(0.99, base + 0.2 * i) for i in range(3)] + [1.0]
+        assert k == O.py_optimal_stopping_rule(P, costs, 30.0)[0]
+    assert len(set(pred.tolist())) >= 2                                  # the population really splits
+    got = pipe.batch_process(prompts)
+    for a, b, k in zip(got, want, pred):
+        assert (a.output, a.stopped_at_stage, a.stage_probabilities, a.stage_costs, a.stages_run) == \
+               (b.output, b.stopped_at_stage, b.stage_probabilities, b.stage_costs, b.stages_run)
+        assert a.predicted_stage == k and b.predicted_stage == -1
+    # one generate() call per (group, stage) and every group enters stage 0 whole
+    sizes = sorted(len(c) for c in sm.stages["8b"].calls)
+    assert sizes == sorted(int((pred == s).sum()) for s in set(pred.tolist()))
+    assert [len(c) for c in sm.stages["8b"].calls] == [int((pred == s).sum()) for s in sorted(set(pred.tolist()))]
+    plain.shutdown()
+    pipe.shutdown()
+
+
+def test_dynamic_lambda_rule_matches_the_reference_and_drives_the_pipeline(golden):
+    """optimize_lambda_parameter == DynamicCostOptimizer._optimize_lambda_parameter (dynamic_cost_optimizer.py:425-487)
+    bit for bit on 240 reference-generated cases; DynamicLambdaController feeds it from pipeline.get_stats()."""
+    from asd_amd.algorithms.optimizer import DynamicLambdaController, optimize_lambda_parameter
+    for c in golden.json("dynamic_lambda.json"):
+        got = optimize_lambda_parameter(c["current_lambda"], c["metrics"], c["gpu_utilization"], c["request_rate"],
+                                        c["load_forecast"])
+        assert got == c["new_lambda"], c
+    pipe, sm = _pipeline("full", lam=1.0, risk_adjustment=False)
+    pipe.batch_process(["easy a", "hard a", "mid a"])
+    ctl = DynamicLambdaController(pipe, [1.0, 1.6, 4.2, 8.8], target_latency=1e9, min_quality=0.0)
+    m = ctl.metrics()
+    assert set(m) == {"avg_latency", "avg_quality", "avg_cost"} and m["avg_cost"] >= 1.0
+    new = ctl.step(gpu_utilization=[0.5, 0.5])
+    # latency far below target (+0.05), quality above min, cost >= 1 ... : whatever the sum, the pipeline follows it
+    assert pipe.config.lambda_value == new == optimize_lambda_parameter(1.0, m, [0.5, 0.5], 0.0, [], 1e9, 0.0)
+    assert ctl.history == [(1.0, new)]
     pipe.shutdown()
 
 
