@@ -143,8 +143,13 @@ class _SeqState:
 # ------------------------------------------------------------------------------------------- tier 0
 class DraftRole:
     def __init__(self, model, cfg: HierarchyConfig, ops, prompt_ids: torch.Tensor, max_new_tokens: int, predictor,
-                 feat: Optional[torch.Tensor] = None):
+                 feat: Optional[torch.Tensor] = None, batch_total: Optional[int] = None, batch_offset: int = 0):
+        """batch_total / batch_offset: this role drafts sequences [offset, offset + B) of a batch of `batch_total`
+        (replicated drafts, BASELINE configs[4]); its uniforms are the matching slice of the full batch's draws, so
+        the stream does not depend on how the batch is cut over ranks."""
         self.m, self.cfg, self.ops = model, cfg, ops
+        self.batch_total = batch_total if batch_total is not None else prompt_ids.shape[0]
+        self.batch_offset = batch_offset
         self.st = _SeqState(prompt_ids, max_new_tokens, cfg.draft_len)
         dev = prompt_ids.device
         B, K = self.st.B, cfg.draft_len
@@ -176,7 +181,7 @@ class DraftRole:
             self.d_logits = torch.empty((B, K, dl.shape[-1]), dtype=dl.dtype, device=dl.device)
         for k in range(K):
             self.d_logits[:, k] = dl
-            r = torch.rand((B,), generator=self.gen, device=dl.device)
+            r = torch.rand((self.batch_total,), generator=self.gen, device=dl.device)[self.batch_offset:self.batch_offset + B].contiguous()
             t, lp, thr = self.ops.draft_sample(self.d_logits[:, k], r, self.inv_t, cfg.top_p)
             self.tok[:, k], self.lp_d[:, k], self.thr[:, k] = t, lp, thr
             if k + 1 < K:
@@ -379,9 +384,12 @@ class VerifyRole:
         return ((v.stop == 1) & (v.n_acc < self.cfg.draft_len)).nonzero()[:, 0]
 
     @torch.no_grad()
-    def draw(self, b_rows: torch.Tensor, d_rows: torch.Tensor, d_thr: torch.Tensor) -> torch.Tensor:
+    def draw(self, b_rows: torch.Tensor, d_rows: torch.Tensor, d_thr: torch.Tensor,
+             only: Optional[Tuple[int, int]] = None) -> torch.Tensor:
         """The token every sequence that STOPPED at this tier commits after its accepted prefix -> drawn [B] i32
-        (0 elsewhere).  b_rows / d_rows / d_thr: DraftRole.rows_for of this tier's verdict."""
+        (0 elsewhere).  b_rows / d_rows / d_thr: DraftRole.rows_for of this tier's verdict.  only = (b0, b1): draw
+        for sequences b0 <= b < b1 only (the rank's own slice under replicated drafts; the target rows are still
+        gathered for every stopping sequence, the gather being a collective of the tier's ranks)."""
         B, dev, K = self.st.B, self.st.tokens.device, self.cfg.draft_len
         drawn = torch.zeros((B,), dtype=torch.int32, device=dev)
         if self._pending is None:
@@ -394,6 +402,12 @@ class VerifyRole:
         b_sel = idx[sel]
         j = n_acc.to(torch.int64)[sel]
         t_rows = self.head.draw_rows(sel, j)                # [m, V]: row n_acc (the bonus row when n_acc == K)
+        if only is not None:
+            mine = (b_sel >= only[0]) & (b_sel < only[1])
+            b_sel, j, t_rows = b_sel[mine], j[mine], t_rows[mine].contiguous()
+            m = b_sel.numel()
+            if m == 0:
+                return drawn
         d_full = torch.zeros_like(t_rows)
         thr = torch.full((m,), float("-inf"), dtype=torch.float32, device=dev)
         if b_rows.numel():
@@ -718,3 +732,51 @@ def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: Hie
             head = LogitsHead(m, ops)
         tiers[s] = VerifyRole(m, s, cfg, ops, prompt_ids, max_new_tokens, predictor, head=head, keep_inputs=keep_inputs)
     return draft, tiers
+
+
+# ---- BASELINE configs[4]: replicated drafts + ONE vocab-sharded target over all ranks -------------------------
+@torch.no_grad()
+def run_sharded_target_rank(rank: int, world: int, draft: DraftRole, target: VerifyRole, b0: int, b1: int, device,
+                            max_steps: int, group=None) -> HierarchyTrace:
+    """Every rank drafts its own slice [b0, b1) of the batch with its own copy of the draft tier; the target tier's
+    lm_head is split along the vocabulary over ALL ranks (`target.head` is a ShardedHead over `group`, its body is
+    replicated -- tensor-parallel model execution is third-party in the reference), so every rank scores the whole
+    batch.  Per step the ranks exchange
+
+        all-gather  tok [B/N,K] i32, lp_d [B/N,K] f32, p_0 [B/N] f64              (replicated drafts -> everyone)
+        all-gather  (m2, s, g) [B,K,3] f32 per rank                                (inside ShardedHead.score)
+        all-gather  the shard pieces of ONE target row per sequence [B, V/N]       (inside ShardedHead.draw_rows)
+        all-gather  drawn [B/N] i32                                                (each rank draws for its own slice)
+
+    and never a [B,K,V] tensor.  Two tiers (L = 2): the target's verdict is final."""
+    from ..distributed import all_gather_any
+    Bl = b1 - b0
+    L = draft.L
+    assert L == 2 and target.s == 1
+    tr = HierarchyTrace(target.st.tokens, target.st.seq_len, tier_counts=[0] * L, tier_calls=[0] * L)
+    K = draft.cfg.draft_len
+    while tr.steps < max_steps:
+        dm_l = draft.propose()
+        tok = torch.cat(all_gather_any(dm_l.tok, group), 0)
+        lp_d = torch.cat(all_gather_any(dm_l.lp_d, group), 0)
+        p0 = torch.cat(all_gather_any(dm_l.p0, group), 0)
+        dm = DraftMsg(tok, lp_d, p0, torch.zeros((tok.shape[0],), dtype=torch.uint8, device=device))
+        v, _ = target.verify(dm, None)
+        v_local = Verdict(v.active[b0:b1], v.stop[b0:b1], v.n_acc[b0:b1])
+        bl, d_rows, d_thr = draft.rows_for(v_local)
+        tr.rows_shipped += int(bl.numel())
+        drawn = target.draw(bl + b0, d_rows, d_thr, only=(b0, b1))
+        drawn_all = torch.cat(all_gather_any(drawn[b0:b1].contiguous(), group), 0)
+        final = FinalMsg(v.n_acc.contiguous(), drawn_all.contiguous(), torch.ones_like(v.n_acc))
+        before = int(target.st.seq_len.sum().item())
+        draft.commit(dm_l, FinalMsg(final.n_acc[b0:b1].contiguous(), final.drawn[b0:b1].contiguous(),
+                                    final.tier[b0:b1].contiguous()))
+        target.commit(dm, final)
+        tr.verified_tokens += int(target.st.seq_len.sum().item()) - before
+        tr.tier_counts[1] += int(tok.shape[0])
+        tr.tier_calls[1] += int(tok.shape[0])
+        tr.steps += 1
+        if int(target.st.seq_len.min().item()) >= target.st.cap:
+            break
+    tr.fed_tokens = [target.fed_tokens]
+    return tr

@@ -304,6 +304,72 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
     return rec
 
 
+def sharded_target_loop(torch, dist, device, rank, world, shapes, B_local, K, prompt_len, warmup, steps, logit_scale=0.6, seed=5):
+    """BASELINE configs[4]: every rank drafts its own B_local sequences (replicated draft tier), the target tier's
+    lm_head is vocabulary-sharded over ALL ranks (asd_lm_head_partial + [B,K,3] all-gather; the body is replicated:
+    tensor-parallel model execution is third-party).  Weak scaling: the batch grows with the ranks."""
+    from asd_amd.minimal_adaptive_decoder import MinimalQualityPredictor
+    from asd_amd.serving import hierarchy as H
+    from asd_amd.serving.synthetic_lm import QWEN25_SHAPES, SyntheticLM, tiny
+
+    table = dict(QWEN25_SHAPES, tiny=tiny())
+    d_shape, t_shape = table[shapes[0]], table[shapes[-1]]
+    V = t_shape.vocab
+    Bt = B_local * world
+    b0, b1 = B_local * rank, B_local * (rank + 1)
+    torch.manual_seed(0)
+    pred = MinimalQualityPredictor().eval()
+    new_tokens = (warmup + steps + 3) * (K + 1)
+    g = torch.Generator(device=device).manual_seed(seed)
+    prompt = torch.randint(0, V, (Bt, prompt_len), generator=g, device=device)
+    cfg = H.HierarchyConfig(draft_len=K, temperature=0.7, top_p=0.9, stage_costs=(1.0, 10.0), lambda_value=1.0, seed=seed)
+    ops = _timed_ops(torch)
+    t0 = time.perf_counter()
+    dm = SyntheticLM(d_shape, dtype=torch.bfloat16, device=device, seed=1, logit_scale=logit_scale)
+    draft = H.DraftRole(dm, cfg, ops, prompt[b0:b1].contiguous(), new_tokens, pred, batch_total=Bt, batch_offset=b0)
+    tm = SyntheticLM(t_shape, dtype=torch.bfloat16, device=device, seed=3, logit_scale=logit_scale)
+    head = H.ShardedHead(tm, ops, V, group=None)
+    tm.lm_head.weight = torch.nn.Parameter(tm.lm_head.weight[head.v0:head.v1].clone(), requires_grad=False)
+    torch.cuda.empty_cache()
+    target = H.VerifyRole(tm, 1, cfg, ops, prompt, new_tokens, pred, head=head)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    red = torch.device("cpu") if dist.get_backend() == "gloo" else device
+
+    def barrier():
+        dist.all_reduce(torch.zeros(1, device=red))
+
+    if warmup:
+        H.run_sharded_target_rank(rank, world, draft, target, b0, b1, device, max_steps=warmup)
+    ops.totals_ms()
+    head.bytes_exchanged = 0
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr = H.run_sharded_target_rank(rank, world, draft, target, b0, b1, device, max_steps=steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hot = ops.totals_ms()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank != 0:
+        return None
+    hot_ms = sum(v[0] for v in hot.values())
+    return {
+        "tiers": [d_shape.name, t_shape.name], "placement": f"replicated {d_shape.name} drafts on every rank + {t_shape.name} "
+        f"target with a vocab-sharded lm_head over {world} rank(s)", "batch_total": Bt, "batch_per_rank": B_local,
+        "draft_len": K, "prompt_len": prompt_len, "steps": tr.steps, "warmup": warmup, "verified_tokens": tr.verified_tokens,
+        "seconds": elapsed, "verified_tokens_per_s": tr.verified_tokens / elapsed, "ms_per_step": 1e3 * elapsed / max(1, tr.steps),
+        "tokens_per_sequence_step": tr.verified_tokens / max(1, tr.steps * Bt),
+        "bytes_exchanged_per_step_rank0": head.bytes_exchanged / max(1, tr.steps),
+        "hot_path_ms_per_step": hot_ms / max(1, tr.steps), "hot_path_share": hot_ms / (1e3 * elapsed),
+        "hot_path_calls": {k: {"ms": v[0], "calls": v[1]} for k, v in hot.items()}, "build_s": build_s,
+        "models": f"synthetic random-weight Qwen2.5 shapes, logit_scale {logit_scale}; target body replicated on every rank",
+    }
+
+
 LM_HEADS = {"7b": 3584, "14b": 5120, "32b": 5120, "72b": 8192}   # Qwen2.5 hidden sizes (configs/models.yaml)
 MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16
 
@@ -466,8 +532,21 @@ def main_tiers(args):
     B = args.loop_batch
     steps = args.steps if args.steps != 1000 else 8
     warmup = args.warmup if args.warmup != 300 else 2
-    rec = hierarchy_loop(torch, dist, device, rank, world, args.tier_shapes.split(","), B, K, 32, warmup, steps, lam=args.lam,
-                         target_stop_rate=args.stop_rate)
+    sharded = args.placement == "sharded-target"
+    if sharded:
+        if world == 1:                                  # the sharded head talks to a process group even when it is alone
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group(args.dist_backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                    **({"device_id": device} if args.dist_backend == "nccl" else {}))
+        if B == 32:
+            B = 16                                      # configs[4]: batch 128 over 8 GPUs
+        rec = sharded_target_loop(torch, dist, device, rank, world, args.tier_shapes.split(","), B, K, 32, warmup, steps)
+    else:
+        rec = hierarchy_loop(torch, dist, device, rank, world, args.tier_shapes.split(","), B, K, 32, warmup, steps,
+                             lam=args.lam, target_stop_rate=args.stop_rate)
     if rank == 0:
         torch.cuda.empty_cache()
         nbuf = 3
@@ -489,12 +568,14 @@ def main_tiers(args):
         out = {
             "metric": "verified_tokens_per_s", "value": rec["verified_tokens_per_s"], "unit": "tokens/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"tiers: token-level loop, {'/'.join(rec['tiers'])} placed over {world} rank(s), batch {B}, "
-                                   f"draft_len {K}, vocab {V}; step = draft K tokens (asd_draft_sample) + tier verify "
-                                   "(asd_verify_accept / asd_lm_head_verify) + asd_predictor_stop + escalation + "
+            "scaling": "weak" if sharded else "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": (f"sharded-target: token-level loop, replicated {rec['tiers'][0]} drafts + {rec['tiers'][-1]} target "
+                                    f"vocab-sharded over {world} rank(s), batch {B} per rank" if sharded else
+                                    f"tiers: token-level loop, {'/'.join(rec['tiers'])} placed over {world} rank(s), batch {B}")
+                                   + f", draft_len {K}, vocab {V}; step = draft K tokens (asd_draft_sample) + tier verify "
+                                   "(asd_verify_accept / asd_lm_head_verify / asd_lm_head_partial) + asd_predictor_stop + escalation + "
                                    "asd_residual_sample_ex + asd_commit_step; synthetic random-weight models",
-                       "batch": B, "draft_len": K, "vocab": V, "parallelism": f"tiers over {world} rank(s)",
+                       "batch": B, "draft_len": K, "vocab": V, "parallelism": f"{args.placement} over {world} rank(s)",
                        "placement": rec["placement"]},
             "roofline": {"bound": "hbm", "achieved": nbytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": nbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -503,11 +584,52 @@ def main_tiers(args):
             "loop": rec,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
+def _quiet_rccl_banner():
+    """This image exports NCCL_DEBUG=VERSION, which makes RCCL print a version banner on STDOUT at communicator
+    creation -- in front of the one JSON line the driver parses.  Anything chattier than that is left alone."""
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+        os.environ["NCCL_DEBUG"] = "WARN"
+
+
+def sharded_verify_step(torch, dist, device, rank, world, B, K, V, D=8192, reps=30):
+    """The one exchange step of a vocab-sharded target over the ranks of this job (BASELINE configs[4]'s hot path
+    without the models): every rank reduces its [V/N, D] slice of a 72B-shape lm_head to (m2, s, g) triples
+    (asd_lm_head_partial, bf16 MFMA, no logits), ONE all-gather of [B,K,3] floats over RCCL, asd_accept_from_partials.
+    Returns the per-step time (max over ranks) and the bytes a rank sends."""
+    from asd_amd.distributed import VocabShardedVerifier
+    ver = VocabShardedVerifier(V)
+    g = torch.Generator(device=device).manual_seed(77)
+    hid = torch.randn((B, K, D), generator=g, device=device).to(torch.bfloat16)
+    gw = torch.Generator(device=device).manual_seed(1000 + rank)
+    w = (torch.randn((ver.v1 - ver.v0, D), generator=gw, device=device) * (3.0 / D ** 0.5)).to(torch.bfloat16)
+    tok = torch.randint(0, V, (B, K), generator=g, device=device, dtype=torch.int32)
+    lp_d = -torch.rand((B, K), generator=g, device=device) * 2
+    u = torch.rand((B, K), generator=g, device=device)
+    for _ in range(5):
+        out = ver.verify_hidden(hid, w, tok, lp_d, u)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = ver.verify_hidden(hid, w, tok, lp_d, u)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    red = torch.device("cpu") if dist.get_backend() == "gloo" else device
+    t = torch.tensor([dt], dtype=torch.float64, device=red)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n_acc = out[2]
+    return {"what": "vocab-sharded verify step: asd_lm_head_partial on a [V/N, 8192] lm_head shard + all-gather [B,K,3] f32 "
+                    "+ asd_accept_from_partials", "ranks": world, "batch": B, "draft_len": K, "vocab": V, "hidden": D,
+            "us_per_step": 1e6 * float(t.item()), "bytes_sent_per_rank_per_step": B * K * 12 * (world - 1),
+            "tokens_per_step": int(n_acc.sum().item()) + B, "backend": dist.get_backend()}
+
+
 def main():
+    _quiet_rccl_banner()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -535,11 +657,13 @@ def main():
                     help="gloo + ASD_BENCH_ONE_DEVICE=1 rehearses the N>1 control flow with every rank on cuda:0")
     ap.add_argument("--lm-head", choices=sorted(LM_HEADS), default=None,
                     help="start the step from hidden states: asd_lm_head_verify with this Qwen2.5 lm_head size (N2)")
-    ap.add_argument("--placement", choices=["replicas", "tiers"], default="replicas",
+    ap.add_argument("--placement", choices=["replicas", "tiers", "sharded-target"], default="replicas",
                     help="replicas (default): every rank runs the kernel step on its own batch (the headline metric, weak "
                          "scaling).  tiers: the token-level loop with the 7B / 32B / 72B hierarchy placed over the ranks "
                          "(BASELINE configs[3]; 1 rank: all on one GPU, 2: {7B+32B | 72B}, >= 4: 7B | 32B | 72B with a "
-                         "vocab-sharded lm_head), stop rule live, small messages point-to-point over RCCL")
+                         "vocab-sharded lm_head), stop rule live, small messages point-to-point over RCCL.  sharded-target: "
+                         "BASELINE configs[4] -- every rank drafts --loop-batch sequences with its own 7B, the 72B target's "
+                         "lm_head is vocab-sharded over all ranks ([B,K,3] all-gather per step); weak scaling")
     ap.add_argument("--tier-shapes", default="7b,32b,72b", help="Qwen2.5 shapes of the tiers (or tiny,tiny,tiny)")
     ap.add_argument("--loop-batch", type=int, default=32)
     ap.add_argument("--loop-steps", type=int, default=6, help="steps of the bounded `loop` sub-record of the default run")
@@ -550,7 +674,7 @@ def main():
     args = ap.parse_args()
     if args.lm_head:
         return main_lm_head(args)
-    if args.placement == "tiers":
+    if args.placement in ("tiers", "sharded-target"):
         return main_tiers(args)
 
     import numpy as np
@@ -799,6 +923,21 @@ def main():
             loop_rec = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
 
+    pending_watchdog = None
+    state = {"out": None}
+    if distributed and not args.no_loop:
+        # N > 1: the exchange step of a vocab-sharded target over THIS job's ranks (RCCL all-gather + the HIP kernels).
+        # Bounded by a watchdog: if the collective hangs, every rank leaves and rank 0 still prints the headline.
+        import threading
+
+        def bail():
+            if rank == 0 and state["out"] is not None:
+                state["out"]["sharded_verify"] = {"error": "timed out after 120 s"}
+                print(json.dumps(state["out"]), flush=True)
+            os._exit(0)
+        pending_watchdog = threading.Timer(120.0, bail)
+        pending_watchdog.daemon = True
+
     if rank == 0:
         achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
         traffic, traffic_src = load_traffic()
@@ -842,6 +981,21 @@ def main():
             out["loop"] = loop_rec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, torch, cpu_buf, B, K, V, weights, feat_np, args.cpu_budget_s)
+    else:
+        out = None
+    if pending_watchdog is not None:
+        state["out"] = out
+        pending_watchdog.start()
+        try:
+            bufs = cpu_buf = None
+            torch.cuda.empty_cache()
+            sharded_rec = sharded_verify_step(torch, dist, device, rank, world, B, K, V)
+        except Exception as e:  # noqa: BLE001
+            sharded_rec = {"error": f"{type(e).__name__}: {e}"}
+        pending_watchdog.cancel()
+        if out is not None:
+            out["sharded_verify"] = sharded_rec
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -220,6 +220,60 @@ def test_tiers_on_different_ranks_commit_the_single_process_stream(world):
         assert dict(ret) == {r: "ok" for r in range(world)}
 
 
+def _sharded_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from asd_amd.serving import hierarchy as H
+        from tests.oracle_backend import OracleOps
+        solos = [dist.new_group([r]) for r in range(world)]             # collective: every rank creates every group
+        Bt = 8
+        prompt = torch.randint(0, V, (Bt, P), generator=torch.Generator().manual_seed(11))
+        cfg = H.HierarchyConfig(draft_len=K, temperature=0.7, top_p=0.9, stage_costs=(1.0, 10.0), lambda_value=1.0, seed=4)
+
+        def run(group, n, r):
+            ops, pred = OracleOps(), _predictor()
+            b0, b1 = Bt * r // n, Bt * (r + 1) // n
+            d = H.DraftRole(_model(0, 0), cfg, ops, prompt[b0:b1], NEW, pred, batch_total=Bt, batch_offset=b0)
+            m = _model(0.03, 9)
+            head = H.ShardedHead(m, ops, V, group=group)
+            m.lm_head.weight = torch.nn.Parameter(m.lm_head.weight[head.v0:head.v1].clone(), requires_grad=False)
+            t = H.VerifyRole(m, 1, cfg, ops, prompt, NEW, pred, head=head)
+            return H.run_sharded_target_rank(r, n, d, t, b0, b1, "cpu", max_steps=NEW + 4, group=group), head
+
+        want, _ = run(solos[rank], 1, 0)                                # the whole batch on one rank
+        got, head = run(None, world, rank)                              # replicated drafts, target sharded over all ranks
+        assert torch.equal(got.tokens, want.tokens) and torch.equal(got.seq_len, want.seq_len)
+        assert (got.seq_len == P + NEW).all() and got.steps == want.steps
+        accepted = got.verified_tokens - got.steps * Bt
+        assert accepted > 0                                             # some drafted tokens were accepted
+        # exchange volume per rank: triples + one row piece per sequence and step, never a [B,K,V] tensor
+        per_step = head.bytes_exchanged / got.steps
+        assert per_step <= (Bt * K * 12 + Bt * (V // world + 1) * 4) * (world - 1) + 64
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_replicated_drafts_with_a_vocab_sharded_target(world):
+    """BASELINE configs[4] in miniature: every rank drafts its slice, the target's lm_head is split over all ranks;
+    the committed stream equals the one-rank run's."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        assert dict(ret) == {r: "ok" for r in range(world)}
+
+
 def test_placements_follow_the_reference_yaml():
     from asd_amd.serving.hierarchy import Placement
     assert Placement.for_world(1).tiers == [[0], [0]]
