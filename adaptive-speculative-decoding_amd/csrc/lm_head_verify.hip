@@ -407,6 +407,184 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     }
 }
 
+// ---- M <= 64 rows (B*K <= 64: BASELINE configs[1], batch 8 x draft_len 8): the call is HBM-bound (64 flop per weight byte),
+// so the tile is shaped for the STREAM, not for the MFMA pipe: the 8 waves sit side by side on the 256 vocabulary columns of a
+// block (32 columns each, all 64 rows), the hidden slot shrinks to 8 KiB, and the LDS that frees goes into deeper rings --
+// 4 weight slots + 3 hidden slots (152 KiB).  Loads are issued  H(S+2), W(S+3)  behind the barrier that opens superstage S;
+// because a wave's vmcnt retires in order, the wait for H(S) leaves W(S+1), H(S+1), W(S+2) in flight (9 instructions):
+// TWO whole weight superstages per CU stay outstanding at every barrier instead of one in the 256-row kernel.
+constexpr int kSkWRing = 4;
+constexpr int kSkHRing = 3;
+constexpr int kSkRows = 64;
+
+__global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) {
+    constexpr int BN = 256;
+    constexpr int kWSlot = BN * 128;
+    constexpr int kHSlot = kSkRows * 128;
+    constexpr int WPASSES = BN / 64;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[kSkWRing * kWSlot + kSkHRing * kHSlot];
+    unsigned char* const lds_h = lds + kSkWRing * kWSlot;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wv = t >> 6;          // wave column: vocabulary rows 32 * wv .. of the block
+    const int r = lane & 31;
+    const int h = lane >> 5;
+    const int nb = static_cast<int>(blockIdx.x);
+    const int n0 = p.col0 + nb * BN;
+    const int rows_w = min(BN, p.V - n0);
+    const int rows_h = min(kSkRows, p.M);
+
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    const int drow = wv * 8 + (lane >> 3);
+    const char* const wbase = static_cast<const char*>(p.weight) + static_cast<int64_t>(n0) * p.ld_w * 2;
+    const char* const hbase = static_cast<const char*>(p.hidden);
+    uint32_t woff[WPASSES], hoff;
+#pragma unroll
+    for (int ps = 0; ps < WPASSES; ++ps) {
+        const int row = ps * 64 + drow;
+        const int seg = (lane & 7) ^ ((row >> 1) & 7);
+        woff[ps] = static_cast<uint32_t>(min(row, rows_w - 1)) * static_cast<uint32_t>(p.ld_w * 2) + seg * 16;
+    }
+    {
+        const int seg = (lane & 7) ^ ((drow >> 1) & 7);
+        hoff = static_cast<uint32_t>(min(drow, rows_h - 1)) * static_cast<uint32_t>(p.ld_h * 2) + seg * 16;
+    }
+    const int n_super = p.D / kSuper;
+    auto issue_w = [&](int stage) {
+        const char* src = wbase + static_cast<int64_t>(stage) * (kSuper * 2);
+        asm volatile("" : "+s"(src));
+        unsigned char* dst = lds + (stage % kSkWRing) * kWSlot + wv_s * 1024;
+#pragma unroll
+        for (int ps = 0; ps < WPASSES; ++ps)
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + woff[ps]), (lds_void*)(dst + ps * 8192), 16, 0, 2);
+    };
+    auto issue_h = [&](int stage) {
+        const char* src = hbase + static_cast<int64_t>(stage) * (kSuper * 2);
+        asm volatile("" : "+s"(src));
+        unsigned char* dst = lds_h + (stage % kSkHRing) * kHSlot + wv_s * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void*)(src + hoff), (lds_void*)dst, 16, 0, 0);
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+    const bool wave_works = 32 * wv < rows_w;
+    const int key = (r >> 1) & 7;
+    const int h_off = r * 128;
+    const int w_off = (32 * wv + r) * 128;
+    bf16x8 wf[2], hf[2][2];
+    auto read_frags = [&](int S, int ks, int set) {
+        const unsigned char* wb = lds + (S % kSkWRing) * kWSlot + w_off;
+        const unsigned char* hb = lds_h + (S % kSkHRing) * kHSlot + h_off;
+        const int so = ((4 * h + ks) ^ key) * 16;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) hf[set][mt] = *reinterpret_cast<const bf16x8*>(hb + mt * 32 * 128 + so);
+        wf[set] = *reinterpret_cast<const bf16x8*>(wb + so);
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set], hf[set][mt], acc[mt], 0, 0, 0);
+    };
+    auto compute = [&](int S) {
+        if (!wave_works) return;
+        read_frags(S, 0, 0);
+        read_frags(S, 1, 1);
+        multiply(0);
+        read_frags(S, 2, 0);
+        multiply(1);
+        read_frags(S, 3, 1);
+        multiply(0);
+        multiply(1);
+    };
+    // prologue in steady-state order: W(0) | H(0) W(1) | H(1) W(2)
+    if (0 < n_super) issue_w(0);
+    if (0 < n_super) issue_h(0);
+    if (1 < n_super) issue_w(1);
+    if (1 < n_super) issue_h(1);
+    if (2 < n_super) issue_w(2);
+    int S = 0;
+    for (; S + 3 < n_super; ++S) {          // steady state: W(S+1), H(S+1), W(S+2) stay in flight across the barrier
+        wait_and_meet<2 * WPASSES + 1>();
+        issue_h(S + 2);
+        issue_w(S + 3);
+        compute(S);
+    }
+    for (; S < n_super; ++S) {              // the last three superstages of the block: drain
+        wait_and_meet<0>();
+        if (S + 2 < n_super) issue_h(S + 2);
+        compute(S);
+    }
+
+    // ---- epilogue: per wave 64 rows x 32 columns -> (m2, s, g, arg-max); waves 1..7 hand theirs to wave 0 through LDS
+    float* const meet = reinterpret_cast<float*>(lds);   // [7 waves][64 rows][kMsg]
+    __syncthreads();
+    float tm2[2], ts[2], tg[2], tbv[2];
+    int tbi[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 32 * mt + r;
+        const int tk = (wave_works && m < p.M && p.tok[m] >= p.v_offset) ? p.tok[m] - p.v_offset : -1;
+        float m2 = kSentinel, s = 0.0f, g = -INFINITY, bv = -INFINITY;
+        int bi = kNoIndex;
+        if (wave_works) {
+            float x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = n0 + 32 * wv + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float v = n < p.V ? acc[mt][i] : -INFINITY;
+                if (n == tk) g = v;
+                if (v > bv || (v == bv && n < bi && n < p.V)) { bv = v; bi = n; }
+                x[i] = v;
+            }
+            float lo[8], hi[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { lo[i] = x[i]; hi[i] = x[8 + i]; }
+            accum8(lo, p.c2, m2, s);
+            accum8(hi, p.c2, m2, s);
+        }
+        const float m2o = __shfl_xor(m2, 32, 64);
+        const float so = __shfl_xor(s, 32, 64);
+        const float go = __shfl_xor(g, 32, 64);
+        const float bvo = __shfl_xor(bv, 32, 64);
+        const int bio = __shfl_xor(bi, 32, 64);
+        ms_merge(m2, s, m2o, so);
+        g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));
+        if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+        tm2[mt] = m2; ts[mt] = s; tg[mt] = g; tbv[mt] = bv; tbi[mt] = bi;
+        if (wv != 0 && h == 0) {
+            float* q = meet + ((wv - 1) * kSkRows + m) * kMsg;
+            q[0] = m2; q[1] = s; q[2] = g; q[3] = bv; q[4] = __int_as_float(bi);
+        }
+    }
+    __syncthreads();
+    if (wv != 0 || h != 0) return;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 32 * mt + r;
+        if (m >= p.M) continue;
+        float m2 = tm2[mt], s = ts[mt], g = tg[mt], bv = tbv[mt];
+        int bi = tbi[mt];
+        for (int w = 0; w < 7; ++w) {          // fixed order: deterministic
+            const float* q = meet + (w * kSkRows + m) * kMsg;
+            ms_merge(m2, s, q[0], q[1]);
+            const float go = q[2];
+            g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));
+            const float bvo = q[3];
+            const int bio = __float_as_int(q[4]);
+            if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+        }
+        float* out = p.msg + (static_cast<int64_t>(p.unit0 + nb) * p.M + m) * kMsg;
+        out[0] = m2;
+        out[1] = s;
+        out[2] = g;
+        out[3] = bv;
+        out[4] = __int_as_float(bi);
+    }
+}
+
 // merge the per-block records of every row of sequence b, then the accept rule.  Up to 16 waves; wave w
 // takes draft positions w, w + waves, ...; its lanes stride over the blocks (fixed order: deterministic).
 // greedy != 0: accept[b,k] = (tok[b,k] == argmax_v logits[b,k,v]) instead of the sampling test
@@ -567,6 +745,17 @@ int lm_head_launch(const LmHeadCall& c) {
     p.k_slices = 1;
     hipStream_t st = static_cast<hipStream_t>(c.stream);
     const int hp = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
+    if (M <= kSkRows) {   // the stream-shaped kernel: every 256-column block, one record per block
+        const int64_t blocks = (static_cast<int64_t>(c.V) + 255) / 256;
+        p.col0 = 0;
+        p.unit0 = 0;
+        p.n_blocks = static_cast<int>(blocks);
+        hipLaunchKernelGGL(k_lm_head_skinny, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, p);
+        hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
+                           static_cast<int>(blocks), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
+                           c.lp_target, c.accept, c.n_acc, c.accept_bits, c.argmax_out, c.emit);
+        return launch_status();
+    }
     if (wide > 0) {
         p.col0 = 0;
         p.unit0 = 0;
