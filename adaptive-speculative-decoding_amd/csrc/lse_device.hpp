@@ -63,6 +63,53 @@ static __device__ __forceinline__ void wave_merge(float& m2, float& s) {
     m2 = M;
 }
 
+// ---- (m2, s, t) triples: additionally t = sum_v exp(x_v / T - ...) * x_v on the same scale as s, from which the
+// entropy of the row's softmax follows (N1 / A14: RESEARCH_PROTOCOL.md:378-385): H = ln2 * (m2 + log2 s - c2 * t / s).
+static __device__ __forceinline__ void ms_merge3(float& m2, float& s, float& t, float m2b, float sb, float tb) {
+    const float M = fmaxf(m2, m2b);
+    const float ea = fast_exp2(m2 - M);
+    const float eb = fast_exp2(m2b - M);
+    s = fmaf(s, ea, sb * eb);
+    t = fmaf(t, ea, tb * eb);
+    m2 = M;
+}
+static __device__ __forceinline__ void wave_merge3(float& m2, float& s, float& t) {
+    const float M = wave_max(m2);
+    const float f = fast_exp2(m2 - M);
+    s = wave_sum(s * f);
+    t = wave_sum(t * f);
+    m2 = M;
+}
+// same (m2, s) arithmetic as accum8 / accum4 below, operation for operation (the STATS kernel's verify outputs are
+// bit-identical to the plain kernel's), plus the weighted sum
+template <int N>
+static __device__ __forceinline__ void accum_t(const float (&x)[N], float c2, float& m2, float& s, float& t) {
+    float vmax;
+    if constexpr (N == 8) {
+        vmax = max3(x[0], x[1], x[2]);
+        vmax = max3(vmax, x[3], x[4]);
+        vmax = max3(vmax, x[5], x[6]);
+        vmax = fmaxf(vmax, x[7]);
+    } else {
+        vmax = fmaxf(max3(x[0], x[1], x[2]), x[3]);
+    }
+    const float M = fmaxf(m2, vmax * c2);
+    const float scale = fast_exp2(m2 - M);
+    float e[N];
+    float w = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        e[i] = fast_exp2(fmaf(x[i], c2, -M));
+        w = fmaf(e[i], e[i] > 0.0f ? x[i] : 0.0f, w);      // a -inf logit carries no mass: 0 * -inf must not poison t
+    }
+    float sum;
+    if constexpr (N == 8) sum = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+    else sum = (e[0] + e[1]) + (e[2] + e[3]);
+    s = fmaf(s, scale, sum);
+    t = fmaf(t, scale, w);
+    m2 = M;
+}
+
 // c2 = log2(e) / temperature: the per-element FMA constant, so temperature scaling costs nothing
 static __device__ __forceinline__ void accum_scalar(float x, float c2, float& m2, float& s) {
     const float M = fmaxf(m2, x * c2);
@@ -122,6 +169,15 @@ struct Elem<ASD_DTYPE_BF16> {
         }
         accum8(x, c2, m2, s);
     }
+    static __device__ __forceinline__ void accum3(const u32x4& v, float c2, float& m2, float& s, float& t) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[2 * i] = __uint_as_float(v[i] << 16);
+            x[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+        }
+        accum_t<8>(x, c2, m2, s, t);
+    }
 };
 
 template <>
@@ -150,6 +206,18 @@ struct Elem<ASD_DTYPE_F16> {
         }
         accum8(x, c2, m2, s);
     }
+    static __device__ __forceinline__ void accum3(const u32x4& v, float c2, float& m2, float& s, float& t) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w = v[i];
+            const h2 h = __builtin_bit_cast(h2, w);
+            x[2 * i] = static_cast<float>(h[0]);
+            x[2 * i + 1] = static_cast<float>(h[1]);
+        }
+        accum_t<8>(x, c2, m2, s, t);
+    }
 };
 
 template <>
@@ -169,6 +237,12 @@ struct Elem<ASD_DTYPE_F32> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] = __uint_as_float(v[i]);
         accum4(x, c2, m2, s);
+    }
+    static __device__ __forceinline__ void accum3(const u32x4& v, float c2, float& m2, float& s, float& t) {
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = __uint_as_float(v[i]);
+        accum_t<4>(x, c2, m2, s, t);
     }
 };
 

@@ -85,12 +85,15 @@ struct VerifyParams {
     uint32_t region;     // granules per sequence region
     float scale2;        // log2(e) / temperature
     int mode;            // 0: accept, 1: emit (m2, s, g) partials
+    float* row_max_lp;   // [B,K] out or nullptr: max_v log softmax(x / T)[v]  (= -ln s: free in the epilogue)
+    float* row_entropy;  // [B,K] out or nullptr: entropy (nats) of softmax(x / T); needs the STATS instantiation
     int fused;           // != 0: the sequence's last arriver also runs the predictor / stop epilogue (N1)
     FusedParams epi;     // asd_predictor_stop's parameters (lp / n_valid unused: the kernel's own lp_t, all K)
 };
 
-template <int DT, int UNROLL, bool CHECK>
-__device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, uint32_t end, float c2, float& m2, float& s) {
+template <int DT, int UNROLL, bool CHECK, bool STATS>
+__device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, uint32_t end, float c2, float& m2, float& s,
+                                        float& t) {
     using E = Elem<DT>;
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) {
@@ -100,24 +103,40 @@ __device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, 
             const u32x4 neg = {E::kNegInfWord, E::kNegInfWord, E::kNegInfWord, E::kNegInfWord};
             v = ok ? v : neg;
         }
-        E::accum(v, c2, m2, s);
+        if (STATS) E::accum3(v, c2, m2, s, t);
+        else E::accum(v, c2, m2, s);
     }
 }
 
 // FUSED: compile-time variant that also carries the in-kernel epilogue (N1 second form).  It is a separate
 // instantiation on purpose: the epilogue's prefetch registers and code took the plain kernel from ~40 to 111
 // VGPRs and cost it 6 % (A/B in one process), so the plain kernel does not contain it at all.
+// max_v log softmax(x/T)[v]: the running maximum IS m2 (up to the rounding of x_max * c2, |m2| * 6e-8 in log2 units), so
+// the largest term of s is 1 and the row's top log-probability is -ln s.  s == 0 (nothing but -inf): NaN.
+__device__ __forceinline__ float row_max_logprob(float s) {
+    return s > 0.0f ? static_cast<float>(-kLn2d * log2_split(s)) : NAN;
+}
+// H = -sum p ln p = ln2 * (m2 + log2 s - c2 * t / s)  with  p_v = 2^(x_v c2 - m2) / s,  t = sum 2^(x_v c2 - m2) x_v
+__device__ __forceinline__ float row_entropy_nats(float m2, float s, float t, float c2) {
+    if (!(s > 0.0f)) return NAN;
+    const double L = static_cast<double>(m2) + log2_split(s);
+    return static_cast<float>(kLn2d * (L - static_cast<double>(c2) * static_cast<double>(t) / static_cast<double>(s)));
+}
+
 // The first eight arguments repeat the VerifyParams fields the streaming prologue needs (row base, extents, tok).
 // They are separate scalars ON PURPOSE: this file is compiled with -amdgpu-kernarg-preload-count, so the command
 // processor hands them to every wave in SGPRs at wave start and the first tile loads are issued without waiting for
 // any s_load of the kernarg segment (the by-value struct is fetched meanwhile and first used behind those loads).
-template <int DT, int THREADS, int UNROLL, bool NT, bool FUSED>
+// STATS: additionally carries t = sum e * x through the stream (one more FMA per element, a third slot value per tile)
+// for the row entropy (asd_verify_accept_stats); its own instantiation so that the plain kernel pays nothing.
+template <int DT, int THREADS, int UNROLL, bool NT, bool FUSED, bool STATS = false>
 __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const int32_t* a_tok, int64_t a_ld_row, int a_V,
                                                     int a_K, int a_S, float a_scale2, int a_own, const VerifyParams p) {
     using E = Elem<DT>;
     constexpr int kWaves = THREADS / 64;
     __shared__ uint32_t next_tile;
     __shared__ __attribute__((aligned(16))) uint64_t stage[kMaxStage];   // tile slots while streaming, then scratch of the finisher
+    __shared__ float stage_t[STATS ? kMaxStage : 1];                      // STATS: the tiles' third value
 
     ASD_STAMP_AT(0);
 #ifdef ASD_STAMP
@@ -217,11 +236,15 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     } while (0)
 #define ASD_REDUCE_TILE(reg, t)                                                                          \
     do {                                                                                                 \
-        float tm_ = kSentinel, ts_ = 0.0f;                                                               \
-        if ((t) < n_full) consume<DT, UNROLL, false>(reg, (t) * kTileBytes + lane_off, end, c2, tm_, ts_);   \
-        else consume<DT, UNROLL, true>(reg, (t) * kTileBytes + lane_off, end, c2, tm_, ts_);                 \
-        wave_merge(tm_, ts_);                                                                            \
-        if (lane == 0) stage[(t)] = (static_cast<uint64_t>(__float_as_uint(ts_)) << 32) | __float_as_uint(tm_); \
+        float tm_ = kSentinel, ts_ = 0.0f, tt_ = 0.0f;                                                   \
+        if ((t) < n_full) consume<DT, UNROLL, false, STATS>(reg, (t) * kTileBytes + lane_off, end, c2, tm_, ts_, tt_);   \
+        else consume<DT, UNROLL, true, STATS>(reg, (t) * kTileBytes + lane_off, end, c2, tm_, ts_, tt_);                 \
+        if (STATS) wave_merge3(tm_, ts_, tt_);                                                           \
+        else wave_merge(tm_, ts_);                                                                       \
+        if (lane == 0) {                                                                                 \
+            stage[(t)] = (static_cast<uint64_t>(__float_as_uint(ts_)) << 32) | __float_as_uint(tm_);     \
+            if (STATS) stage_t[(t)] = tt_;                                                               \
+        }                                                                                                \
     } while (0)
 
     bool first = true;
@@ -254,11 +277,23 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         // pin the first use of the loaded values HERE: without it the compiler hoists the (cheap, speculatable)
         // conversions up to the loads and waits for them in front of the loop
         asm volatile("" : "+v"(raw_x), "+v"(raw_head), "+v"(raw_tail), "+v"(raw_lpd), "+v"(raw_u));
-        float hm = kSentinel, hs = 0.0f;
-        if (do_head) accum_scalar(E::from_raw(raw_head), c2, hm, hs);
-        if (do_tail) accum_scalar(E::from_raw(raw_tail), c2, hm, hs);
-        wave_merge(hm, hs);
-        if (lane == 0) stage[n_tiles] = (static_cast<uint64_t>(__float_as_uint(hs)) << 32) | __float_as_uint(hm);
+        float hm = kSentinel, hs = 0.0f, ht = 0.0f;
+        if (do_head) {
+            const float xv = E::from_raw(raw_head);
+            accum_scalar(xv, c2, hm, hs);
+            if (STATS) ht = hs > 0.0f ? hs * xv : 0.0f;      // one element per lane: s = 2^(x c2 - m2) = 1 (or 0 for -inf)
+        }
+        if (do_tail) {
+            const float xv = E::from_raw(raw_tail);
+            accum_scalar(xv, c2, hm, hs);
+            if (STATS) ht = hs > 0.0f ? hs * xv : 0.0f;
+        }
+        if (STATS) wave_merge3(hm, hs, ht);
+        else wave_merge(hm, hs);
+        if (lane == 0) {
+            stage[n_tiles] = (static_cast<uint64_t>(__float_as_uint(hs)) << 32) | __float_as_uint(hm);
+            if (STATS) stage_t[n_tiles] = ht;
+        }
         if (own_row && tid == 0) {
             if (have_x) x_tok = E::from_raw(raw_x);
             if (p.mode == 0) {
@@ -271,12 +306,14 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     // tile slots -> slice: wave 0 folds slots lane, lane+64, ... in order, then across lanes
     __syncthreads();
     if (wave != 0) return;
-    float m2 = kSentinel, s = 0.0f;
+    float m2 = kSentinel, s = 0.0f, tsum = 0.0f;
     for (uint32_t t = static_cast<uint32_t>(lane); t <= n_tiles; t += 64) {
         const uint64_t g = stage[t];
-        ms_merge(m2, s, __uint_as_float(static_cast<uint32_t>(g)), __uint_as_float(static_cast<uint32_t>(g >> 32)));
+        if (STATS) ms_merge3(m2, s, tsum, __uint_as_float(static_cast<uint32_t>(g)), __uint_as_float(static_cast<uint32_t>(g >> 32)), stage_t[t]);
+        else ms_merge(m2, s, __uint_as_float(static_cast<uint32_t>(g)), __uint_as_float(static_cast<uint32_t>(g >> 32)));
     }
-    wave_merge(m2, s);
+    if (STATS) wave_merge3(m2, s, tsum);
+    else wave_merge(m2, s);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the slots are dead; `stage` is reused below
     __builtin_amdgcn_wave_barrier();
     // only wave 0 is left here
@@ -298,6 +335,10 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             const bool flag = finish_row(m2, s, x_tok, c2, lpd, lu_row, lp);
             p.lp_t[row] = lp;
             p.accept[row] = flag ? 1 : 0;
+            if (p.row_max_lp) p.row_max_lp[row] = row_max_logprob(s);
+            if (STATS) {
+                if (p.row_entropy) p.row_entropy[row] = row_entropy_nats(m2, s, tsum, c2);
+            }
             if (fused) {   // hand lp_t to whoever finishes the sequence: write-through store, drained before the ticket
                 __hip_atomic_store(line + kLpLineOffset + k, __float_as_uint(lp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -388,6 +429,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         flag = finish_row(fm, fs, x_tok, c2, lpd, log_u(uu), lp);
         p.lp_t[frow] = lp;
         p.accept[frow] = flag ? 1 : 0;
+        if (p.row_max_lp) p.row_max_lp[frow] = row_max_logprob(fs);
     }
     finish_sequence(flag, lane, p.K, b, p.n_acc, p.bits);
 }
@@ -522,6 +564,20 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     if (grid > INT32_MAX) return ASD_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
+    if (p.row_entropy) {   // the (m2, s, t) instantiation exists for one workgroup per row, 512 lanes x 4-KiB tiles
+        if (g.splits != 1 || g.threads != 512 || g.unroll != 4 || p.K > kFastMaxK || p.fused || p.mode != 0) return ASD_ERR_UNSUPPORTED;
+        const dim3 gd(static_cast<uint32_t>(grid));
+#define ASD_LAUNCH_STATS(DT)                                                                                      \
+    hipLaunchKernelGGL((k_verify<DT, 512, 4, true, false, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row, p.V, \
+                       p.K, p.S, p.scale2, own_row_of(p), p)
+        switch (dtype) {
+            case ASD_DTYPE_BF16: ASD_LAUNCH_STATS(ASD_DTYPE_BF16); break;
+            case ASD_DTYPE_F16: ASD_LAUNCH_STATS(ASD_DTYPE_F16); break;
+            default: ASD_LAUNCH_STATS(ASD_DTYPE_F32); break;
+        }
+#undef ASD_LAUNCH_STATS
+        return launch_status();
+    }
     if (p.fused) {   // the in-kernel epilogue is instantiated for the two geometries the heuristic uses when rows >= CUs
         const dim3 gd(static_cast<uint32_t>(grid));
         const bool big = (g.threads == 1024 && g.unroll == 2);
@@ -605,6 +661,26 @@ ASD_EXPORT int asd_verify_accept_ex(const void* logits, int dtype, int64_t ld_ro
     p.B = B; p.K = K; p.V = V; p.v_offset = 0;
     p.lp_t = lp_target; p.accept = accept; p.n_acc = n_acc; p.bits = accept_bits;
     p.msg = nullptr; p.mode = 0;
+    return launch_verify(p, dtype, workspace, workspace_bytes, stream, g);
+}
+
+ASD_EXPORT int asd_verify_accept_stats(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,
+                                       const float* lp_draft, const float* u, int B, int K, int V, float* lp_target,
+                                       uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits, float* row_max_lp,
+                                       float* row_entropy, void* workspace, size_t workspace_bytes,
+                                       float inv_temperature, void* stream) {
+    if (B > 0 && K > 0 && (!lp_draft || !u || !lp_target || !accept || !n_acc)) return ASD_ERR_INVALID_ARG;
+    asd_verify_options opt{inv_temperature, 0, 0, 0, -1};
+    VerifyParams p{};
+    Geometry g;
+    const int rc = unpack_options(&opt, p.scale2, g);
+    if (rc != ASD_OK) return rc;
+    if (row_entropy) g = Geometry{1, 512, 4, 1};   // one workgroup per row whatever the batch: the entropy's third sum is not handed across slices
+    p.logits = logits; p.ld_row = ld_row; p.tok = tok; p.lp_d = lp_draft; p.u = u;
+    p.B = B; p.K = K; p.V = V; p.v_offset = 0;
+    p.lp_t = lp_target; p.accept = accept; p.n_acc = n_acc; p.bits = accept_bits;
+    p.msg = nullptr; p.mode = 0;
+    p.row_max_lp = row_max_lp; p.row_entropy = row_entropy;
     return launch_verify(p, dtype, workspace, workspace_bytes, stream, g);
 }
 

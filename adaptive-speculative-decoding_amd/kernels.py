@@ -123,6 +123,30 @@ def verify_accept(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tenso
     return out
 
 
+def verify_accept_stats(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
+                        workspace: VerifyWorkspace, out: Optional[VerifyResult] = None, *, inv_temperature: float = 1.0,
+                        want_entropy: bool = True) -> Tuple[VerifyResult, torch.Tensor, Optional[torch.Tensor]]:
+    """asd_verify_accept_stats: the verify pass + per position max log-prob [B,K] and (optionally) the entropy of the
+    target softmax [B,K] -- the device-side inputs of the doc-only FeatureExtractor (RESEARCH_PROTOCOL.md:378-400)."""
+    Bv, K = tok.shape
+    V, ld, ptr = _logits_2d(logits, Bv, K)
+    dev = logits.device
+    if out is None:
+        out = VerifyResult(torch.empty((Bv, K), dtype=torch.float32, device=dev),
+                           torch.empty((Bv, K), dtype=torch.uint8, device=dev),
+                           torch.empty((Bv,), dtype=torch.int32, device=dev),
+                           torch.empty((Bv,), dtype=torch.int64, device=dev))
+    max_lp = torch.empty((Bv, K), dtype=torch.float32, device=dev)
+    ent = torch.empty((Bv, K), dtype=torch.float32, device=dev) if want_entropy else None
+    rc = _lib().asd_verify_accept_stats(
+        ptr, _DTYPE_CODE[logits.dtype], ld, _dev(tok, "tok", torch.int32), _dev(lp_draft, "lp_draft", torch.float32),
+        _dev(u, "u", torch.float32), Bv, K, V, out.lp_target.data_ptr(), out.accept.data_ptr(), out.n_acc.data_ptr(),
+        out.accept_bits.data_ptr(), max_lp.data_ptr(), None if ent is None else ent.data_ptr(), workspace.buf.data_ptr(),
+        workspace.bytes, float(inv_temperature), _stream())
+    B.check("asd_verify_accept_stats", rc)
+    return out, max_lp, ent
+
+
 def lse_partial(logits_shard: torch.Tensor, tok: torch.Tensor, v_offset: int, workspace: VerifyWorkspace,
                 out: Optional[torch.Tensor] = None, inv_temperature: float = 1.0) -> torch.Tensor:
     """Per-shard (m2, s, g) triples, [B,K,3] f32, with sum_v exp(x) = s * 2^m2 (log2 domain)."""

@@ -41,6 +41,31 @@ class FeatureExtractor:
         return feats
 
 
+    @staticmethod
+    def extract_device(row_max_lp: torch.Tensor, row_entropy: torch.Tensor, prompt_words, output_words, stage_id: int,
+                       n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same 256-d vector for a BATCH, from what asd_verify_accept_stats left on the device: row_max_lp /
+        row_entropy [B, T] per verified position (entropy over the whole vocabulary: the k = V form of the doc's top-k
+        sum), prompt_words / output_words [B] (numbers).  No host round trip, no per-token Python.  n_valid [B]: positions
+        that count (default all T); the entropy term averages the last <= 32 of them, as `extract` does."""
+        Bv, T = row_max_lp.shape
+        dev = row_max_lp.device
+        nv = torch.full((Bv,), T, device=dev, dtype=torch.int64) if n_valid is None else n_valid.to(torch.int64)
+        pos = torch.arange(T, device=dev)[None, :]
+        valid = pos < nv[:, None]
+        last = valid & (pos >= (nv - 32).clamp_min(0)[:, None])
+        cnt = nv.clamp_min(1).to(torch.float64)
+        feats = torch.zeros((Bv, FEATURE_DIM), dtype=torch.float64, device=dev)
+        ent = torch.where(last, row_entropy.to(torch.float64), torch.zeros((), dtype=torch.float64, device=dev))
+        feats[:, 0] = ent.sum(1) / last.sum(1).clamp_min(1)
+        mx = torch.where(valid, row_max_lp.to(torch.float64), torch.zeros((), dtype=torch.float64, device=dev))
+        feats[:, 3] = torch.where(nv > 0, mx.sum(1) / cnt, torch.full((Bv,), -10.0, dtype=torch.float64, device=dev))
+        feats[:, 1] = torch.as_tensor(prompt_words, dtype=torch.float64, device=dev) / 2048
+        feats[:, 2] = torch.as_tensor(output_words, dtype=torch.float64, device=dev) / 512
+        feats[:, 4] = stage_id / 4.0
+        return feats.to(torch.float32)
+
+
 class QualityPredictor(nn.Module):
     def __init__(self, feature_dim: int = FEATURE_DIM, hidden_dim: int = 128):
         super().__init__()

@@ -108,6 +108,20 @@ int asd_verify_accept_ex(const void* logits, int dtype, int64_t ld_row,
                          void* workspace, size_t workspace_bytes,
                          const asd_verify_options* opt /*host, may be NULL*/, void* stream);
 
+/* N1, the A14 half: the verify pass that also emits, per verified position, what the missing
+ * FeatureExtractor of docs/guides/RESEARCH_PROTOCOL.md:378-400 derives from per-token log-prob lists on the host:
+ *   row_max_lp[b,k]  = max_v log softmax(logits[b,k]/T)[v]   (the doc's np.max(lp); free: it is -ln s of the running pair)
+ *   row_entropy[b,k] = -sum_v p_v ln p_v  of that softmax      (the doc's -sum exp(lp) * lp taken over the WHOLE vocabulary
+ *                      instead of the top-k list vLLM returns; one more FMA per element in the streaming loop)
+ * Either may be NULL (both NULL == asd_verify_accept_ex with inv_temperature).  With row_entropy the launch is one
+ * workgroup per row whatever the batch and K <= 32 (ASD_ERR_UNSUPPORTED otherwise).  A row without any finite logit
+ * reports NaN for both. */
+int asd_verify_accept_stats(const void* logits, int dtype, int64_t ld_row,
+                            const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
+                            float* lp_target, uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits,
+                            float* row_max_lp /*[B,K] out, may be NULL*/, float* row_entropy /*[B,K] out, may be NULL*/,
+                            void* workspace, size_t workspace_bytes, float inv_temperature, void* stream);
+
 /* Vocab-sharded target (lm_head split over ranks): each rank reduces its [B,K,V_shard] slice,
  * whose first column is global vocab id `v_offset`, to msg[b,k,:] = (m2, s, g) with
  *   sum_v exp(x_v) = s * 2^m2   (log2 domain: m2 = log2(e) * max_v x up to rounding, which cancels),

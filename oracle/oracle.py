@@ -173,6 +173,32 @@ def draft_sample(logits: np.ndarray, dtype: int, r, B: int, V: int, inv_temperat
     return dict(tok=tok, lp=lp, thr=thr, margin_p=mp, margin_r=mr)
 
 
+def row_softmax_stats(logits: np.ndarray, dtype: int, R: int, V: int, inv_temperature: float = 1.0,
+                      ld_row: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """asd_verify_accept_stats' two row statistics in f64: (max_v log softmax(x a)[v], -sum_v p_v ln p_v) per row, the
+    quantities docs/guides/RESEARCH_PROTOCOL.md:378-400 calls np.max(lp) and -np.sum(np.exp(lp) * lp) with `lp` the
+    complete log-prob vector of the position (doc only: not a parity target).  Rows without a finite logit: NaN."""
+    ld = V if ld_row is None else ld_row
+    a = float(np.float32(inv_temperature))
+    flat = np.ascontiguousarray(logits).reshape(-1)
+    mx = np.empty(R)
+    ent = np.empty(R)
+    for r in range(R):
+        x = logits_as_f32(flat[r * ld:r * ld + V], dtype).astype(np.float64) * a
+        m = x.max() if V else -np.inf
+        if not np.isfinite(m):
+            mx[r] = ent[r] = np.nan
+            continue
+        z = x - m
+        e = np.exp(z)
+        s = e.sum()
+        lp = z - np.log(s)
+        mx[r] = lp.max()
+        pos = e > 0
+        ent[r] = -(e[pos] / s * lp[pos]).sum()
+    return mx, ent
+
+
 def py_token_logprob_reference_idiom(score_row_f32: np.ndarray, token_id: int) -> float:
     """generate_training_data.py:131-133 restated with numpy in the row's own precision:
     probs = softmax(score[0]); logprob = log(probs[token_id])."""

@@ -486,3 +486,50 @@ def test_reference_idiom_goldens_at_full_vocabulary(golden):
         assert np.isneginf(got[~fin]).all(), name
         checked += n
     assert checked == 6 + 4 * 12
+
+
+@pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32, O.DT_F16])
+@pytest.mark.parametrize("B,K,V,ld", [(32, 8, 152064, None), (3, 5, 1003, 1010), (8, 8, 32000, None), (2, 32, 4096, None)])
+def test_verify_stats_emit_max_logprob_and_entropy(K_, dtype, B, K, V, ld):
+    """asd_verify_accept_stats (N1, the A14 half): the verify outputs are those of asd_verify_accept_ex bit for bit (same geometry), and
+    per position max log-prob / softmax entropy match the f64 oracle (doc-only quantities: tolerance 2e-5 / 1e-4)."""
+    import torch
+    case = make_verify_case(B, K, V, dtype, seed=V + B, ld_row=ld)
+    x = O.logits_as_f32(case["logits"], dtype).copy()
+    if V > 2000:
+        x[1, 100:V - 100] = -np.inf                      # a top-p style masked row: entropy over the survivors only
+        from tests.helpers import encode_logits
+        case["logits"] = encode_logits(x, dtype)
+        case["ref"] = O.verify_accept(case["logits"], dtype, case["tok"], case["lp_d"], case["u"], B, K, V, ld_row=case["ld"])
+    inv_t = float(np.float32(1 / 0.7))
+    lg = to_device_logits(case["logits"], dtype)
+    lg3 = lg.as_strided((B, K, V), (K * case["ld"], case["ld"], 1))
+    ws = K_.VerifyWorkspace(B, K, V, lg.dtype)
+    tok, lp_d, u = (torch.from_numpy(case[k]).cuda() for k in ("tok", "lp_d", "u"))
+    # the entropy form runs one 512-lane workgroup per row with 4-KiB tiles: bit-identical to the plain kernel AT THAT geometry
+    plain = K_.verify_accept(lg3, tok, lp_d, u, ws, inv_temperature=inv_t, splits=1, threads=512, unroll=4, nontemporal=1)
+    res, max_lp, ent = K_.verify_accept_stats(lg3, tok, lp_d, u, ws, inv_temperature=inv_t)
+    only_max = K_.verify_accept_stats(lg3, tok, lp_d, u, ws, inv_temperature=inv_t, want_entropy=False)
+    torch.cuda.synchronize()
+    for a, b in ((res.lp_target, plain.lp_target), (res.accept, plain.accept), (res.n_acc, plain.n_acc), (res.accept_bits, plain.accept_bits)):
+        assert torch.equal(a, b)
+    want_max, want_ent = O.row_softmax_stats(case["logits"], dtype, B * K, V, inv_t, ld_row=case["ld"])
+    got_max, got_ent = max_lp.cpu().numpy().reshape(-1).astype(np.float64), ent.cpu().numpy().reshape(-1).astype(np.float64)
+    np.testing.assert_allclose(got_max, want_max, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(got_ent, want_ent, atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(only_max[1].cpu().numpy().reshape(-1), want_max, atol=2e-5, rtol=0)
+    assert only_max[2] is None
+    assert (got_ent >= -1e-5).all() and (got_ent <= np.log(V) + 1e-4).all()
+
+
+def test_verify_stats_limits(K_):
+    import torch
+    B, K, V = 2, 40, 512                                   # K > 32: the entropy form is one-workgroup-per-row, ballot-by-atomic only
+    lg = torch.zeros((B, K, V), dtype=torch.bfloat16, device="cuda")
+    ws = K_.VerifyWorkspace(B, K, V)
+    z = torch.zeros((B, K), device="cuda")
+    with pytest.raises(K_.B.AsdError):
+        K_.verify_accept_stats(lg, torch.zeros((B, K), dtype=torch.int32, device="cuda"), z, z + 0.5, ws)
+    r, mx, ent = K_.verify_accept_stats(lg, torch.zeros((B, K), dtype=torch.int32, device="cuda"), z, z + 0.5, ws, want_entropy=False)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(mx.cpu().numpy(), -np.log(V), atol=1e-5)      # a flat row: every log-prob is -ln V

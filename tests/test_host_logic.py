@@ -505,3 +505,20 @@ def test_grid_search_population_table(oracle_backend, golden):
     assert t["costs"] == [float(np.mean(c)) for c in g["cost"]]
     assert t["stage_distributions"][-1] == np.bincount(g["k_star"][-1], minlength=4).tolist()
     assert len(t["latencies"]) == len(g["lam"]) and t["latencies"][0] == t["costs"][0] * 100.0
+
+
+def test_a14_features_from_device_statistics_equal_the_host_extractor():
+    """FeatureExtractor.extract_device (inputs: what asd_verify_accept_stats leaves on the device) == FeatureExtractor.extract
+    (the doc's per-token Python, RESEARCH_PROTOCOL.md:366-409) when the per-token lists are whole log-prob vectors."""
+    import torch
+    from asd_amd.serving.components import FeatureExtractor
+    B, T, V = 4, 45, 64
+    lps = [[np.log(np.random.default_rng(b * 100 + t).dirichlet(np.ones(V))) for t in range(T)] for b in range(B)]
+    n_valid = [45, 33, 7, 0]
+    fx = FeatureExtractor()
+    host = np.stack([fx.extract("a b c d", "x y z", lps[b][:n_valid[b]], 3) for b in range(B)])
+    mx = torch.tensor([[lp.max() for lp in lps[b]] for b in range(B)], dtype=torch.float32)
+    en = torch.tensor([[-(np.exp(lp) * lp).sum() for lp in lps[b]] for b in range(B)], dtype=torch.float32)
+    dev = FeatureExtractor.extract_device(mx, en, [4] * B, [3] * B, 3, n_valid=torch.tensor(n_valid))
+    np.testing.assert_allclose(dev.numpy(), host, atol=2e-6, rtol=0)
+    assert dev.shape == (B, 256) and dev[3, 3] == -10.0 and dev[3, 0] == 0.0
