@@ -49,6 +49,8 @@ SIGNATURES = {
                                 _sz, _vp]),
     "asd_lm_head_verify_ex": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _sz, _vp]),
+    "asd_lm_head_packed_bytes": (_sz, [_i, _i]),
+    "asd_lm_head_pack_weights": (_i, [_vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     "asd_lm_head_partial": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
     "asd_commit_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),
     "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),

@@ -65,6 +65,7 @@ struct LmHeadParams {
     int v_offset;        // global vocabulary id of column 0 (a vocabulary shard of a tensor-parallel lm_head)
     int col0;            // first vocabulary column of this launch
     int unit0;           // index of this launch's first block in msg (one record per row and block)
+    int packed;          // != 0: `weight` is the tile-major image of asd_lm_head_pack_weights ([V/256][D/64][256 rows][64 cols])
     int k_slices;        // > 1: every column block is cut into this many reduction slices (one workgroup each)
     float* slabs;        // [n_blocks][k_slices][8 waves][2 * NTW * 4][64 lanes] float4: partial accumulators
     uint32_t* tickets;   // [n_blocks], zero before the launch; the slice that draws k_slices - 1 finishes the block
@@ -129,14 +130,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     // spends no vector instructions on addressing (SQ counters: the DMA issue was ~8 % of an iteration).
     const int wv_s = __builtin_amdgcn_readfirstlane(wv);   // wave id as a scalar: LDS destinations stay in SGPRs
     const int drow = wv * 8 + (lane >> 3);
-    const char* const wbase = static_cast<const char*>(p.weight) + static_cast<int64_t>(n0) * p.ld_w * 2;
+    // weights as given ([V][ld_w]: a superstage of a block is 256 strided 128-byte lines, every one in another DRAM page)
+    // or packed tile-major (asd_lm_head_pack_weights: the block's superstage is ONE contiguous 32 KiB run)
+    const int64_t w_stage_stride = p.packed ? 256 * 128 : kSuper * 2;
+    const uint32_t w_row_stride = p.packed ? 128u : static_cast<uint32_t>(p.ld_w * 2);
+    const char* const wbase = p.packed
+        ? static_cast<const char*>(p.weight) + (static_cast<int64_t>(n0 / 256) * (p.D / kSuper)) * (256 * 128) + static_cast<int64_t>(n0 % 256) * 128
+        : static_cast<const char*>(p.weight) + static_cast<int64_t>(n0) * p.ld_w * 2;
     const char* const hbase = static_cast<const char*>(p.hidden) + static_cast<int64_t>(m0) * p.ld_h * 2;
     uint32_t woff[WPASSES], hoff[HPASSES];
 #pragma unroll
     for (int ps = 0; ps < WPASSES; ++ps) {
         const int row = ps * 64 + drow;
         const int seg = (lane & 7) ^ ((row >> 1) & 7);
-        woff[ps] = static_cast<uint32_t>(min(row, rows_w - 1)) * static_cast<uint32_t>(p.ld_w * 2) + seg * 16;
+        woff[ps] = static_cast<uint32_t>(min(row, rows_w - 1)) * w_row_stride + seg * 16;
     }
 #pragma unroll
     for (int ps = 0; ps < HPASSES; ++ps) {
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     const int s_begin = p.k_slices > 1 ? min(slice * per_slice, total_super) : 0;
     const int n_super = p.k_slices > 1 ? min(s_begin + per_slice, total_super) : total_super;
     auto issue_w = [&](int stage) {
-        const char* src = wbase + static_cast<int64_t>(stage) * (kSuper * 2);
+        const char* src = wbase + static_cast<int64_t>(stage) * w_stage_stride;
         asm volatile("" : "+s"(src));   // keep the base in SGPRs: without it LLVM folds the lane offset into a 64-bit VGPR pointer
         unsigned char* dst = lds + (stage % kWRing) * kWSlot + wv_s * 1024;
 #pragma unroll
@@ -436,14 +443,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) 
 
     const int wv_s = __builtin_amdgcn_readfirstlane(wv);
     const int drow = wv * 8 + (lane >> 3);
-    const char* const wbase = static_cast<const char*>(p.weight) + static_cast<int64_t>(n0) * p.ld_w * 2;
+    const int64_t w_stage_stride = p.packed ? 256 * 128 : kSuper * 2;
+    const uint32_t w_row_stride = p.packed ? 128u : static_cast<uint32_t>(p.ld_w * 2);
+    const char* const wbase = p.packed
+        ? static_cast<const char*>(p.weight) + (static_cast<int64_t>(n0 / 256) * (p.D / kSuper)) * (256 * 128)
+        : static_cast<const char*>(p.weight) + static_cast<int64_t>(n0) * p.ld_w * 2;
     const char* const hbase = static_cast<const char*>(p.hidden);
     uint32_t woff[WPASSES], hoff;
 #pragma unroll
     for (int ps = 0; ps < WPASSES; ++ps) {
         const int row = ps * 64 + drow;
         const int seg = (lane & 7) ^ ((row >> 1) & 7);
-        woff[ps] = static_cast<uint32_t>(min(row, rows_w - 1)) * static_cast<uint32_t>(p.ld_w * 2) + seg * 16;
+        woff[ps] = static_cast<uint32_t>(min(row, rows_w - 1)) * w_row_stride + seg * 16;
     }
     {
         const int seg = (lane & 7) ^ ((drow >> 1) & 7);
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) 
     }
     const int n_super = p.D / kSuper;
     auto issue_w = [&](int stage) {
-        const char* src = wbase + static_cast<int64_t>(stage) * (kSuper * 2);
+        const char* src = wbase + static_cast<int64_t>(stage) * w_stage_stride;
         asm volatile("" : "+s"(src));
         unsigned char* dst = lds + (stage % kSkWRing) * kWSlot + wv_s * 1024;
 #pragma unroll
@@ -656,6 +667,24 @@ __global__ __launch_bounds__(1024) void k_accept_from_blocks(const float* msg, i
     finish_sequence(flag, lane, K, b, n_acc, bits);
 }
 
+// [V][ld_w] bf16 -> tile-major [ceil(V/256)][D/64][256][64]: thread = one 16-byte segment; rows >= V are zero
+__global__ __launch_bounds__(256) void k_pack_lm_head(const char* __restrict__ w, int64_t ld_w, int V, int D,
+                                                      char* __restrict__ out, int64_t n_segments) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n_segments) return;
+    const int n_super = D / kSuper;
+    const int seg = static_cast<int>(i & 7);                 // 8 segments of 16 B per 128-byte row piece
+    const int64_t line = i >> 3;                              // (block, superstage, row)
+    const int row = static_cast<int>(line & 255);
+    const int64_t bs = line >> 8;
+    const int st = static_cast<int>(bs % n_super);
+    const int64_t blk = bs / n_super;
+    const int64_t v = blk * 256 + row;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (v < V) val = *reinterpret_cast<const u32x4*>(w + (v * ld_w + static_cast<int64_t>(st) * kSuper) * 2 + seg * 16);
+    *reinterpret_cast<u32x4*>(out + i * 16) = val;
+}
+
 // upper bound of the column blocks of one call (all of them narrow)
 inline int max_blocks_for(int V) { return (V + 127) / 128; }
 
@@ -709,7 +738,8 @@ int lm_head_launch(const LmHeadCall& c) {
         if (!c.lp_target || !c.accept || !c.n_acc) return ASD_ERR_INVALID_ARG;
         if (!c.greedy && (!c.lp_draft || !c.u)) return ASD_ERR_INVALID_ARG;
     }
-    if (c.ld_h < c.D || c.ld_w < c.D) return ASD_ERR_INVALID_ARG;
+    const bool packed = c.ld_w == 0;       // ld_w == 0: `weight` is the image written by asd_lm_head_pack_weights
+    if (c.ld_h < c.D || (!packed && c.ld_w < c.D)) return ASD_ERR_INVALID_ARG;
     if (!aligned_to(c.hidden, 16) || !aligned_to(c.weight, 16) || c.ld_h % 8 != 0 || c.ld_w % 8 != 0) return ASD_ERR_ALIGNMENT;
     if (!c.workspace || c.workspace_bytes < asd_lm_head_verify_workspace_bytes(c.B, c.K, c.V)) return ASD_ERR_WORKSPACE;
     if (!aligned_to(c.workspace, 16)) return ASD_ERR_ALIGNMENT;
@@ -742,6 +772,7 @@ int lm_head_launch(const LmHeadCall& c) {
     p.c2 = static_cast<float>(1.4426950408889634074 * static_cast<double>(c.inv_temperature));
     p.msg = static_cast<float*>(c.workspace);
     p.m_blocks = static_cast<int>(m_blocks);
+    p.packed = packed ? 1 : 0;
     p.k_slices = 1;
     hipStream_t st = static_cast<hipStream_t>(c.stream);
     const int hp = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
@@ -812,4 +843,24 @@ ASD_EXPORT int asd_lm_head_partial(const void* hidden, int64_t ld_h, const void*
     return lm_head_launch(LmHeadCall{hidden, ld_h, weight_shard, ld_w, dtype, D, tok, nullptr, nullptr, B, K, V_shard,
                                      v_offset, inv_temperature, 0, nullptr, nullptr, nullptr, nullptr, nullptr, msg,
                                      workspace, workspace_bytes, stream});
+}
+
+ASD_EXPORT size_t asd_lm_head_packed_bytes(int V, int D) {
+    if (V <= 0 || D <= 0 || D % kSuper != 0) return 0;
+    return static_cast<size_t>((V + 255) / 256) * static_cast<size_t>(D / kSuper) * 256 * 128;
+}
+
+ASD_EXPORT int asd_lm_head_pack_weights(const void* weight, int64_t ld_w, int dtype, int V, int D, void* packed,
+                                        size_t packed_bytes, void* stream) {
+    if (V < 1 || D < 1 || !weight || !packed || ld_w < D) return ASD_ERR_INVALID_ARG;
+    if (dtype != ASD_DTYPE_BF16 || D % kSuper != 0) return ASD_ERR_UNSUPPORTED;
+    if (!aligned_to(weight, 16) || !aligned_to(packed, 16) || ld_w % 8 != 0) return ASD_ERR_ALIGNMENT;
+    const size_t need = asd_lm_head_packed_bytes(V, D);
+    if (packed_bytes < need) return ASD_ERR_WORKSPACE;
+    const int64_t n_seg = static_cast<int64_t>(need / 16);
+    const int64_t blocks = (n_seg + 255) / 256;
+    if (blocks >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_pack_lm_head, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const char*>(weight), ld_w, V, D, static_cast<char*>(packed), n_seg);
+    return launch_status();
 }

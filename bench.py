@@ -415,7 +415,7 @@ def main_lm_head(args):
         tok[:, ::2] = (h[::2].float() @ w.float().T).argmax(-1).reshape(B, -1)[:, : tok[:, ::2].shape[1]].to(torch.int32)
         bufs.append(dict(h=h, tok=tok, lp_d=-torch.rand((B, K), device=device, generator=g) * 2,
                          u=torch.rand((B, K), device=device, generator=g), out=None))
-    ver = Kmod.LmHeadVerifier(w, B, K)
+    ver = Kmod.LmHeadVerifier(w, B, K, packed=True)      # tile-major copy of the matrix (asd_lm_head_pack_weights)
     packed = Kmod.pack_mlp_weights(*predictor_weights(np), device=device)
     feat = torch.from_numpy((np.random.default_rng(7).standard_normal((B, 64)) * 0.3).astype(np.float32)).to(device)
     Cc = torch.tensor(STAGE_COSTS, dtype=torch.float64, device=device)
@@ -467,7 +467,7 @@ def main_lm_head(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload} from hidden states: {desc.split(';')[0]}; step = asd_lm_head_verify "
-                                   f"({args.lm_head} lm_head, D={D}: bf16 MFMA GEMM + log-sum-exp + accept, no logits in HBM)"
+                                   f"({args.lm_head} lm_head, D={D}, packed tile-major: bf16 MFMA GEMM + log-sum-exp + accept, no logits in HBM)"
                                    + ("" if args.verify_only else " + asd_predictor_stop"),
                        "batch_per_gpu": B, "draft_len": K, "vocab": V, "hidden": D, "accumulate": "f32 MFMA (epilogue f64)",
                        "rotating_buffers": nbuf, "launch_mode": "eager",

@@ -169,6 +169,15 @@ int asd_lm_head_verify_ex(const void* hidden, int64_t ld_h, const void* weight, 
                           uint64_t* accept_bits, int32_t* argmax_out /*[B,K] out, may be NULL*/,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Optional one-time re-layout of an lm_head matrix for the three calls above and below (like asd_mlp_pack_weights for
+ * the predictor): [V][ld_w] bf16 -> tile-major [ceil(V/256)][D/64][256 rows][64 columns], rows past V zero.  A column
+ * block's 64-deep reduction step is then ONE contiguous 32 KiB run instead of 256 lines that sit D*2 bytes apart (each
+ * in another DRAM page).  Pass the packed image as `weight` with ld_w = 0; results are bit-identical to the unpacked call.
+ * For a vocabulary shard (asd_lm_head_partial) pack the shard's rows.  packed: asd_lm_head_packed_bytes(V, D) bytes. */
+size_t asd_lm_head_packed_bytes(int V, int D);
+int asd_lm_head_pack_weights(const void* weight, int64_t ld_w, int dtype, int V, int D, void* packed /*out*/,
+                             size_t packed_bytes, void* stream);
+
 /* Tensor-parallel lm_head (weight split over ranks along the vocabulary): this rank's [V_shard, D] slice,
  * whose row 0 is global vocabulary id v_offset, reduced straight to the asd_lse_partial message
  * msg[b,k,:] = (m2, s, g); all-gather the messages and finish with asd_accept_from_partials.  The

@@ -99,6 +99,35 @@ def test_lm_head_verify_matches_oracle(B, K, D, V):
     check(run_gpu(case), case["ref"])
 
 
+@pytest.mark.parametrize("B,K,D,V", [(3, 5, 64, 300), (8, 8, 256, 1000), (32, 8, 512, 4173), (40, 8, 128, 33000),
+                                     (32, 8, 128, 66000), (32, 8, 4608, 65536 + 3 * 256 - 56), (16, 8, 192, 129)])
+def test_packed_weights_give_bit_identical_results(B, K, D, V):
+    """asd_lm_head_pack_weights: the tile-major image (ld_w = 0) through every kernel variant -- skinny (M <= 64), wide and
+    narrow blocks, two row blocks, split-K tail tiles -- returns exactly what the [V, D] matrix returns."""
+    import torch
+
+    from asd_amd import kernels as Kn
+
+    case = make_case(B, K, D, V, seed=B + V)
+    w, h = bf16_dev(case["wb"]), bf16_dev(case["hb"])
+    args = (h, torch.from_numpy(case["tok"]).cuda(), torch.from_numpy(case["lp_d"]).cuda(), torch.from_numpy(case["u"]).cuda())
+    am1 = torch.empty((B, K), dtype=torch.int32, device="cuda")
+    am2 = torch.empty((B, K), dtype=torch.int32, device="cuda")
+    a = Kn.LmHeadVerifier(w, B, K)(*args, argmax_out=am1)
+    pk = Kn.LmHeadVerifier(w, B, K, packed=True)
+    b = pk(*args, argmax_out=am2)
+    torch.cuda.synchronize()
+    assert torch.equal(a.lp_target, b.lp_target) and torch.equal(a.accept_bits, b.accept_bits) and torch.equal(a.n_acc, b.n_acc)
+    assert torch.equal(am1, am2)
+    check(dict(lp_t=b.lp_target.cpu().numpy(), accept=b.accept.cpu().numpy(), n_acc=b.n_acc.cpu().numpy(),
+               bits=b.accept_bits.cpu().numpy().view(np.uint64)), case["ref"])
+    # the shard message of a tensor-parallel head from a packed shard
+    m1 = Kn.LmHeadVerifier(w, B, K).partial(h, args[1], 0)
+    m2 = pk.partial(h, args[1], 0)
+    torch.cuda.synchronize()
+    assert torch.equal(m1, m2)
+
+
 def test_lm_head_verify_strided_operands_and_temperature():
     case = make_case(4, 7, 128, 777, seed=5, ld_h=136, ld_w=200, inv_t=1.0 / 0.7)
     check(run_gpu(case), case["ref"])

@@ -59,6 +59,8 @@ def main():
         u = torch.rand((B, Kk), device="cuda")
         fused = K.LmHeadVerifier(w, B, Kk)
         out_f = fused(h, tok, lp_d, u)
+        packed = K.LmHeadVerifier(w, B, Kk, packed=True)
+        out_p = packed(h, tok, lp_d, u)
         ws = K.VerifyWorkspace(B, Kk, V, torch.bfloat16)
         logits = torch.empty((M, V), dtype=torch.bfloat16, device="cuda")
         out_t = K.verify_accept(logits.view(B, Kk, V), tok, lp_d, u, ws)
@@ -68,18 +70,20 @@ def main():
             K.verify_accept(logits.view(B, Kk, V), tok, lp_d, u, ws, out=out_t)
 
         t_fused = time_us(lambda: fused(h, tok, lp_d, u, out=out_f), a.reps)
+        t_packed = time_us(lambda: packed(h, tok, lp_d, u, out=out_p), a.reps)
         t_gemm = time_us(lambda: torch.matmul(h, w.t(), out=logits), a.reps)
         t_two = time_us(two_step, a.reps)
         flops = 2.0 * M * D * V
         bytes_fused = V * D * 2 + M * D * 2
         bytes_two = bytes_fused + 2 * M * V * 2          # logits written once, read once
-        row = dict(shape=name, D=D, V=V, B=B, K=Kk, fused_us=t_fused, gemm_only_us=t_gemm, two_step_us=t_two,
-                   fused_tflops=flops / t_fused / 1e6, gemm_tflops=flops / t_gemm / 1e6,
+        row = dict(shape=name, D=D, V=V, B=B, K=Kk, fused_us=t_fused, fused_packed_us=t_packed, gemm_only_us=t_gemm,
+                   two_step_us=t_two, fused_tflops=flops / t_fused / 1e6, fused_packed_tflops=flops / t_packed / 1e6,
+                   fused_packed_hbm_gbs=bytes_fused / t_packed / 1e3, gemm_tflops=flops / t_gemm / 1e6,
                    fused_hbm_gbs=bytes_fused / t_fused / 1e3, two_step_hbm_gbs=bytes_two / t_two / 1e3,
                    speedup_vs_two_step=t_two / t_fused)
         rows.append(row)
         print(json.dumps(row), flush=True)
-        del h, w, logits, fused, ws
+        del h, w, logits, fused, packed, ws
         torch.cuda.empty_cache()
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
