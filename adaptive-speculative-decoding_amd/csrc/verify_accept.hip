@@ -24,9 +24,9 @@
 // payload store, no drain, no read-back on the tail.
 //
 // Split rows (S > 1; few rows, many CUs).
-// Hand-off.  The slice result is published as ONE 8-byte granule (write-through, agent scope),
-// the publishing lane drains its store (s_waitcnt vmcnt(0)) and takes a ticket on the
-// sequence's counter.  The workgroup whose ticket is the last of the sequence's K*S tickets
+// Hand-off.  The slice result is published as ONE self-tagging 8-byte granule (write-through, agent
+// scope; never all-zero, an empty slot is) and the publishing lane takes a ticket on the
+// sequence's counter without draining the store (round 2: the drain was a round trip on every tail).  The workgroup whose ticket is the last of the sequence's K*S tickets
 // stages the K*S granules of the K candidate rows in LDS, combines the S slices of every row in
 // slice order (=> bitwise deterministic, independent of arrival order), gathers the drafted
 // token's logit, runs the acceptance test, and turns the K accept flags into the sequence's
@@ -383,9 +383,13 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     uint32_t* ticket = p.tickets + static_cast<int64_t>(b) * kTicketStride;
     int last = 0;
     if (lane == 0) {
+        // a granule is never all-zero bits (s > 0, or m2 is the sentinel), an EMPTY slot is: the granule tags itself.
+        // So the store is not drained before the ticket (that was one store-ack round trip on every slice's tail):
+        // the finisher re-reads a slot until it is non-zero -- every store it waits for was ISSUED before the ticket
+        // add whose return value made it the finisher, so the wait is bounded by one store latency -- and hands the
+        // slot back empty.
         const uint64_t g = (static_cast<uint64_t>(__float_as_uint(s)) << 32) | __float_as_uint(m2);
         __hip_atomic_store(region + k * S + split, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = (old == static_cast<uint32_t>(KS - 1));
     }
@@ -400,8 +404,15 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             x_tok = E::scalar(static_cast<const char*>(p.logits) + static_cast<int64_t>(frow) * p.ld_row * E::kBytes, t);
         if (p.mode == 0) { lpd = p.lp_d[frow]; uu = p.u[frow]; }
     }
-    for (int g = lane; g < KS; g += 64)
-        stage[g] = __hip_atomic_load(region + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int g = lane; g < KS; g += 64) {
+        uint64_t v = __hip_atomic_load(region + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spins = 0; v == 0ull && spins < (1 << 20); ++spins) {   // in flight, not lost: see the publishing side
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(region + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        stage[g] = v;
+        __hip_atomic_store(region + g, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // empty again for the next call
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
