@@ -4,6 +4,7 @@ loop, decoder, table, sharding logic) on a box without a GPU.
 TEST INFRASTRUCTURE: lives under tests/, is installed with asd_amd.set_backend() by fixtures only,
 and is never importable from the package.  Numbers it produces say nothing about the product."""
 import numpy as np
+import torch
 
 from oracle import oracle as O
 
@@ -115,37 +116,7 @@ class OracleOps:
         return torch.from_numpy(lp.astype(np.float32)), torch.from_numpy(acc), torch.from_numpy(n_acc), torch.from_numpy(bits)
 
 
-# ---- the rest of a tier step (asd_amd.serving.hierarchy), by the oracle on CPU tensors ----------------------
-def _np_store(t):
-    import torch
-    if t.dtype in (torch.bfloat16, torch.float16):
-        return t.contiguous().view(torch.int16).numpy().view(np.uint16), (O.DT_BF16 if t.dtype == torch.bfloat16 else O.DT_F16)
-    return t.float().contiguous().numpy(), O.DT_F32
-
-
-def oracle_predictor_stop(weights, lp, feat, p_hist, stage_idx, costs, lam, risk_adjustment=True, n_obs=100, alpha=1.0,
-                          beta=1.0, stats_col=5):
-    """asd_predictor_stop restated with the oracle's pieces (numpy in / numpy out): A7 stats -> feature overlay ->
-    A8 MLP -> A2 Bayes -> p_hist[:, stage_idx] -> A1 DP rule over all L stages."""
-    w1, b1, w2, b2 = weights
-    lp = np.asarray(lp, dtype=np.float32)
-    x = np.array(feat, dtype=np.float32, copy=True)
-    stats = O.logprob_stats(lp, None, K=lp.shape[1])
-    if stats_col >= 0:
-        x[:, stats_col:stats_col + 5] = stats.astype(np.float32)
-    score = O.mlp_predict(x, w1, b1, np.asarray(w2).reshape(-1), b2)
-    p = score.astype(np.float64)
-    if risk_adjustment:
-        p = O.bayes_adjust(p, n_obs, alpha, beta)
-    hist = np.array(p_hist, dtype=np.float64, copy=True)
-    hist[:, stage_idx] = p
-    k_star, _ = O.optimal_stopping(hist, np.asarray(costs, dtype=np.float64), float(lam))
-    return score, k_star, hist
-
-
-def _extend_oracle_ops():
-    import torch
-
+    # ---- the rest of a tier step (asd_amd.serving.hierarchy)
     def lm_head_verify(self, hidden, weight, tok, lp_d, u, inv_temperature=1.0):
         """f64 product of the operands as stored (bf16 or f32), then the A5 rule on x * inv_temperature."""
         B, K = tok.shape
@@ -190,8 +161,30 @@ def _extend_oracle_ops():
     def lambda_sweep(self, p_hist, costs, lams):
         return torch.from_numpy(O.lambda_sweep(p_hist.numpy(), costs.numpy(), lams.numpy())[0])
 
-    for f in (lm_head_verify, pack_predictor, predictor_stop, draft_sample, residual_sample, commit_step, lambda_sweep):
-        setattr(OracleOps, f.__name__, f)
+
+# ---- the rest of a tier step (asd_amd.serving.hierarchy), by the oracle on CPU tensors ----------------------
+def _np_store(t):
+    import torch
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.contiguous().view(torch.int16).numpy().view(np.uint16), (O.DT_BF16 if t.dtype == torch.bfloat16 else O.DT_F16)
+    return t.float().contiguous().numpy(), O.DT_F32
 
 
-_extend_oracle_ops()
+def oracle_predictor_stop(weights, lp, feat, p_hist, stage_idx, costs, lam, risk_adjustment=True, n_obs=100, alpha=1.0,
+                          beta=1.0, stats_col=5):
+    """asd_predictor_stop restated with the oracle's pieces (numpy in / numpy out): A7 stats -> feature overlay ->
+    A8 MLP -> A2 Bayes -> p_hist[:, stage_idx] -> A1 DP rule over all L stages."""
+    w1, b1, w2, b2 = weights
+    lp = np.asarray(lp, dtype=np.float32)
+    x = np.array(feat, dtype=np.float32, copy=True)
+    stats = O.logprob_stats(lp, None, K=lp.shape[1])
+    if stats_col >= 0:
+        x[:, stats_col:stats_col + 5] = stats.astype(np.float32)
+    score = O.mlp_predict(x, w1, b1, np.asarray(w2).reshape(-1), b2)
+    p = score.astype(np.float64)
+    if risk_adjustment:
+        p = O.bayes_adjust(p, n_obs, alpha, beta)
+    hist = np.array(p_hist, dtype=np.float64, copy=True)
+    hist[:, stage_idx] = p
+    k_star, _ = O.optimal_stopping(hist, np.asarray(costs, dtype=np.float64), float(lam))
+    return score, k_star, hist
