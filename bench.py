@@ -893,18 +893,35 @@ def main():
             # needs thousands of launches for that, 300 left the B=8 figure 30 % above its steady state)
             for i in range(max(400, int(25e-3 / (ob / 4.0e12)))):
                 overify(obufs[i % onb])
-            oreps = 200
+            # a B=8 launch (8 us) is shorter than a Python ctypes call: time replays of a hipGraph of the launches
+            # (same kernels, same rotating buffers), eager only if capture is refused (e.g. under a profiler)
+            og, per = None, min(onb, 24)
+            try:
+                torch.cuda.synchronize()
+                og = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(og):
+                    for i in range(per):
+                        overify(obufs[i % onb])
+                og.replay()
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                og = None
+            oreps = 10 if og is not None else 200
             oruns = []
             for _ in range(5):
                 e0.record()
                 for i in range(oreps):
-                    overify(obufs[i % onb])
+                    if og is not None:
+                        og.replay()
+                    else:
+                        overify(obufs[i % onb])
                 e1.record()
                 torch.cuda.synchronize()
-                oruns.append(e0.elapsed_time(e1) / oreps)
+                oruns.append(e0.elapsed_time(e1) / (oreps * (per if og is not None else 1)))
+            del og
             oms = sum(oruns) / len(oruns)
             others[name] = {"batch": oB, "draft_len": oK, "vocab": oV, "algorithmic_bytes": ob, "kernel_ms_mean": oms,
-                            "kernel_ms_runs": oruns, "achieved_GBs": ob / (oms * 1e-3) / 1e9,
+                            "kernel_ms_runs": oruns, "launch": "hipGraph replays of back-to-back launches", "achieved_GBs": ob / (oms * 1e-3) / 1e9,
                             "frac_of_8TBs": ob / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             del obufs, ows
             torch.cuda.empty_cache()

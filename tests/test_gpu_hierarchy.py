@@ -170,3 +170,145 @@ def test_stage0_cascade_and_lambda_extremes_on_gpu():
         tr = H.generate_hierarchical(d, ts)
         assert check(tr), (lam, min_stage, tr.tier_counts)
         assert (tr.seq_len == P + NEW).all()
+
+
+# ---- the multi-rank drivers with the HIP kernels: two / three ranks sharing cuda:0, messages staged over gloo ----------
+def _gpu_rank_worker(rank, world, port, mode, ret):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from tests.test_hierarchy import ROOT, _model, _predictor, _prompt
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from asd_amd.distributed import HipOps
+        from asd_amd.serving import hierarchy as H
+        dev = torch.device("cuda", 0)
+        dt = torch.bfloat16
+        if mode == "tiers":
+            cfg = H.HierarchyConfig(draft_len=K, temperature=0.7, top_p=0.9, lambda_value=25.0, seed=3)
+            prompt = _prompt().to(dev)
+
+            def build(pl, r, group_ranks):
+                ops, pred = HipOps(), _predictor()
+                draft = H.DraftRole(_model(0, 0, dt, dev), cfg, ops, prompt, NEW, pred) if r == pl.draft else None
+                tiers = {}
+                for s, (noise, seed) in enumerate(((0.02, 5), (0.04, 6)), start=1):
+                    if r in pl.ranks_of(s):
+                        m = _model(noise, seed, dt, dev)
+                        tiers[s] = H.VerifyRole(m, s, cfg, ops, prompt, NEW, pred, head=H.LogitsHead(m, ops))
+                return draft, tiers
+            d1, t1 = build(H.Placement.for_world(1), 0, None)
+            want = H.generate_hierarchical(d1, [t1[1], t1[2]])
+            pl = H.Placement.for_world(world)
+            d, t = build(pl, rank, None)
+            got = H.run_hierarchical_rank(rank, pl, d, t, B, K, 3, V, dt, P + NEW, dev)
+            assert torch.equal(got.tokens, want.tokens) and got.tier_counts == want.tier_counts
+            assert 0 < got.tier_counts[1] < sum(got.tier_counts)
+            if rank == pl.draft:
+                assert got.bytes_sent.get("rows", 0) <= got.rows_shipped * (V * 2 + 4) * len(pl.ranks_of(2))
+        else:                                   # replicated drafts + vocab-sharded target (BASELINE configs[4])
+            solos = [dist.new_group([r]) for r in range(world)]
+            Bt = 8
+            g = torch.Generator().manual_seed(11)
+            prompt = torch.randint(0, V, (Bt, P), generator=g).to(dev)
+            cfg = H.HierarchyConfig(draft_len=K, temperature=0.7, top_p=0.9, stage_costs=(1.0, 10.0), seed=4)
+
+            def run(group, n, r):
+                ops, pred = HipOps(), _predictor()
+                b0, b1 = Bt * r // n, Bt * (r + 1) // n
+                d = H.DraftRole(_model(0, 0, dt, dev), cfg, ops, prompt[b0:b1].contiguous(), NEW, pred, batch_total=Bt, batch_offset=b0)
+                m = _model(0.03, 9, dt, dev)
+                head = H.ShardedHead(m, ops, V, group=group)
+                m.lm_head.weight = torch.nn.Parameter(m.lm_head.weight[head.v0:head.v1].clone(), requires_grad=False)
+                t = H.VerifyRole(m, 1, cfg, ops, prompt, NEW, pred, head=head)
+                return H.run_sharded_target_rank(r, n, d, t, b0, b1, dev, max_steps=NEW + 4, group=group)
+            want = run(solos[rank], 1, 0)
+            got = run(None, world, rank)
+            # the shard merge order differs from the one-shard run in the last bits of lp_t only: same decisions, same stream
+            assert torch.equal(got.tokens, want.tokens), "sharded-target stream differs from the one-rank run"
+            assert (got.seq_len == P + NEW).all()
+        torch.cuda.synchronize()
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "tiers"), (3, "tiers"), (2, "sharded")])
+def test_multi_rank_drivers_with_hip_kernels_on_one_gpu(world, mode):
+    """The multi-rank loops with HipOps: `world` processes share cuda:0, the small messages are staged through the host over
+    gloo (distributed.host_staged).  Same protocol, same kernels as an RCCL run on `world` GPUs (which a one-GPU box
+    cannot host); the committed stream must equal the single-process GPU loop's."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_gpu_rank_worker, args=(r, world, port, mode, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+        alive = [p for p in procs if p.is_alive()]
+        for p in alive:
+            p.kill()
+        assert not alive and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def test_three_tier_loop_at_the_production_vocabulary():
+    """The same loop with V = 152064 (Qwen2.5) rows: every kernel of the step at the size the path runs at -- nucleus
+    select over 152064 logits, verify from [n, K, 152064] bf16 logits and from hidden states, residual draws."""
+    import torch
+    from asd_amd.distributed import HipOps
+    from asd_amd.serving import hierarchy as H
+    from tests.test_hierarchy import _model, _predictor
+    VV, NEWV = 152064, 12
+    cfg = H.HierarchyConfig(draft_len=K, temperature=0.7, top_p=0.9, lambda_value=25.0, seed=3)
+    ops, pred = HipOps(), _predictor()
+    prompt = torch.randint(0, VV, (B, P), generator=torch.Generator().manual_seed(7)).cuda()
+    dt = torch.bfloat16
+    d = H.DraftRole(_model(0, 0, dt, "cuda", VV), cfg, ops, prompt, NEWV, pred)
+    m1, m2 = _model(0.02, 5, dt, "cuda", VV), _model(0.04, 6, dt, "cuda", VV)
+    ts = [H.VerifyRole(m1, 1, cfg, ops, prompt, NEWV, pred, head=H.LogitsHead(m1, ops), keep_inputs=True),
+          H.VerifyRole(m2, 2, cfg, ops, prompt, NEWV, pred, head=H.FusedHead(m2, ops), keep_inputs=True)]
+    tr = H.generate_hierarchical(d, ts, keep_inputs=True)
+    assert (tr.seq_len == P + NEWV).all() and sum(tr.tier_counts) == tr.steps * B
+    costs = np.array(cfg.stage_costs)
+    inv_t = np.float32(1 / 0.7)
+    checked = 0
+    lens = np.full(B, P)
+    buf = np.zeros((B, P + NEWV), np.int32)
+    buf[:, :P] = prompt.cpu().numpy()
+    for rec in tr.records:
+        dm, final = rec["draft"], rec["final"]
+        assert int(dm.tok.min()) >= 0 and int(dm.tok.max()) < VV and float(dm.lp_d.max()) <= 1e-6
+        for s in (1, 2):
+            if s not in rec["tiers"]:
+                continue
+            v, drawn = rec["tiers"][s]
+            inp, n = v.inputs, v.idx.numel()
+            tok, lp_d, u = (inp[k].cpu().numpy() for k in ("tok", "lp_d", "u"))
+            if "logits" in inp:
+                ref = O.verify_accept(_store(inp["logits"])[0].reshape(n * K, VV), O.DT_BF16, tok, lp_d, u, n, K, VV,
+                                      inv_temperature=inv_t, n_threads=8)
+                np.testing.assert_allclose(inp["lp_t"].cpu().numpy(), ref["lp_t64"], atol=1e-5, rtol=1e-6)
+                safe = ref["margin"] >= 1e-4
+                assert np.array_equal(v.accept.cpu().numpy()[safe], ref["accept"][safe])
+                checked += int(safe.sum())
+            hist = v.p_hist.cpu().numpy()
+            ks, _ = O.optimal_stopping(hist, costs, cfg.lambda_value)
+            assert np.array_equal(v.k_star.cpu().numpy(), ks)
+            assert 0 <= int(drawn.min()) and int(drawn.max()) < VV
+        tokc = dm.tok.cpu().numpy()
+        for b in range(B):
+            new = (list(tokc[b, :int(final.n_acc[b])]) + [int(final.drawn[b])])[: max(0, P + NEWV - lens[b])]
+            buf[b, lens[b]:lens[b] + len(new)] = new
+            lens[b] += len(new)
+    assert np.array_equal(buf, tr.tokens.cpu().numpy()) and checked > 20

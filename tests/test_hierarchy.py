@@ -27,9 +27,9 @@ V, B, P, NEW, K = 1000, 6, 5, 24, 4
 LAM_MIX = 25.0         # with the predictor below: ~70 % of the blocks stop at tier 1, ~30 % escalate
 
 
-def _model(noise, seed, dtype=torch.float32, device="cpu"):
+def _model(noise, seed, dtype=torch.float32, device="cpu", vocab=V):
     from asd_amd.serving.synthetic_lm import SyntheticLM, tiny
-    m = SyntheticLM(tiny(vocab=V), dtype=dtype, device=device, seed=1, logit_scale=4.0)
+    m = SyntheticLM(tiny(vocab=vocab), dtype=dtype, device=device, seed=1, logit_scale=4.0)
     if noise:
         g = torch.Generator().manual_seed(seed)
         with torch.no_grad():
