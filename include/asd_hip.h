@@ -328,7 +328,8 @@ int asd_residual_sample_ex(const void* t_logits, int64_t ld_t, const void* d_log
  *   lp[b]  = log q(tok[b])                                       (the lp_draft the verify step needs; may be NULL)
  *   nucleus_logit[b] = x*_b (-inf without truncation; may be NULL): with it asd_residual_sample_ex reconstructs q exactly.
  * logits: [B rows][V] of `dtype`, rows ld ELEMENTS apart, 16-byte aligned, a whole number of 16-byte vectors.
- * Rows must not contain NaN / +inf.  workspace: asd_draft_sample_workspace_bytes, 256-byte aligned, no initialisation.
+ * Rows must not contain NaN / +inf.  One launch, one 1024-lane workgroup per row (the row stays in its CU's L2 / LDS
+ * reach); V*sizeof(elem) <= 2 MiB.  workspace: unused since 0.2 (asd_draft_sample_workspace_bytes returns 256; may be NULL).
  * ---------------------------------------------------------------------------------------- */
 size_t asd_draft_sample_workspace_bytes(int B, int V, int dtype);
 int asd_draft_sample(const void* logits, int64_t ld, int dtype, const float* r /*[B]*/, int B, int V,

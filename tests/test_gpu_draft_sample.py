@@ -68,6 +68,40 @@ def test_draft_sample_matches_oracle(K_, dtype, B, V, top_p, T):
         assert np.isneginf(thr).all()
 
 
+@pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32])
+def test_draft_sample_flat_and_peaked_rows_in_one_batch(K_, dtype):
+    """The kernel lists a row's candidates (tokens above the (1 - top_p) / V mass floor) in LDS when they fit and sweeps the
+    row when they do not: one batch holds rows of both kinds (flat rows: ~every token is a candidate) and rows in between."""
+    B, V = 8, 152064
+    rng = np.random.default_rng(77)
+    scales = np.array([0.02, 3.0, 0.5, 6.0, 1.0, 0.1, 1.5, 2.0], np.float32)
+    x = rng.standard_normal((B, V)).astype(np.float32) * scales[:, None]
+    r = rng.uniform(0, 1, B).astype(np.float32)
+    store = encode_logits(x, dtype)
+    inv_t = float(np.float32(1.0 / 0.7))
+    ref = O.draft_sample(store, dtype, r, B, V, inv_t, 0.9)
+    tok, lp, thr = _gpu(K_, store, r, B, V, dtype, inv_t, 0.9)
+    ok_p = ref["margin_p"] > 1e-5
+    assert ok_p.sum() >= 2
+    assert np.array_equal(thr[ok_p], ref["thr"][ok_p])
+    ok = ok_p & (ref["margin_r"] > 1e-5)
+    assert np.array_equal(tok[ok], ref["tok"][ok])
+    np.testing.assert_allclose(lp[ok], ref["lp"][ok], rtol=1e-6, atol=LP_ATOL)
+    xs = O.logits_as_f32(store, dtype)
+    assert (xs[np.arange(B), tok] >= thr).all()
+    # a flat f32 row has no token of mass > 1e-5, so top_p is never 1e-5 away from a cumulative-mass step and the exact
+    # threshold is not pinned; what holds for EVERY row: the reported nucleus is the smallest one reaching top_p, to 1e-5
+    for b in range(B):
+        z = xs[b].astype(np.float64) * inv_t
+        pr = np.exp(z - z.max())
+        pr /= pr.sum()
+        assert pr[xs[b] >= thr[b]].sum() >= 0.9 - 1e-5 and pr[xs[b] > thr[b]].sum() < 0.9 + 1e-5
+        lp_ref = np.log(pr[tok[b]] / pr[xs[b] >= thr[b]].sum())
+        assert abs(lp[b] - lp_ref) < 2e-5
+    tok2, lp2, thr2 = _gpu(K_, store, r, B, V, dtype, inv_t, 0.9)
+    assert np.array_equal(tok, tok2) and np.array_equal(lp, lp2) and np.array_equal(thr, thr2)
+
+
 def test_draft_sample_strided_rows_ties_and_masked_logits(K_):
     import torch
     B, V = 6, 4096
