@@ -191,12 +191,19 @@ __global__ __launch_bounds__(64) void k_predictor_stop_w64x32(const FusedParams 
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const bool want_stats = p.lp && (p.stats_col >= 0 || p.stats);
-    int n = p.K;
-    if (want_stats && p.n_valid) n = p.n_valid[b];
-    float lpv = 0.0f;
-    if (want_stats && lane < p.K) lpv = p.lp[static_cast<int64_t>(b) * p.ld_lp + lane];
+    // Every load of the kernel is issued before the first is consumed.  The log-prob and the valid length are kept as raw
+    // bits behind an empty asm: the compiler otherwise converts lp to f64 right behind its load -- an `s_waitcnt vmcnt(0)`,
+    // one whole memory round trip, in front of the 40 other loads (ISA of the first version).
+    int vb = b;
+    asm volatile("" : "+v"(vb));          // vector loads: nothing here waits on the scalar path
+    uint32_t raw_n = static_cast<uint32_t>(p.K), raw_lp = 0u;
+    if (want_stats && p.n_valid) raw_n = reinterpret_cast<const uint32_t*>(p.n_valid)[vb];
+    if (want_stats && lane < p.K) raw_lp = reinterpret_cast<const uint32_t*>(p.lp)[static_cast<int64_t>(vb) * p.ld_lp + lane];
     EpiPrefetch e;
     epi_prefetch(p, b, lane, e);
+    asm volatile("" : "+v"(raw_n), "+v"(raw_lp));
+    int n = __builtin_amdgcn_readfirstlane(static_cast<int>(raw_n));
+    const float lpv = __uint_as_float(raw_lp);
     n = n < 0 ? 0 : (n > p.K ? p.K : n);
     epi_finish(p, b, lane, lpv, n, want_stats, e, dvals, xs);
 }

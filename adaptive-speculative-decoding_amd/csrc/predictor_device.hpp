@@ -112,8 +112,33 @@ struct FusedParams {
     float* score; int32_t* k_star; uint8_t* stop; uint8_t* thr_stop; double* stats;
 };
 
+// What the decision tail reads besides the score: the sequence's probability history and the stage costs.  The latency
+// forms fetch them up front (DecidePrefetch, lane 0) so that the tail behind the predictor is arithmetic only -- as loads
+// issued there they were two more dependent memory round trips at the very end of the kernel.
+constexpr int kDecidePrefetch = 4;   // stages whose history / cost are fetched up front (the reference's hierarchies: 3 or 4)
+struct DecidePrefetch {
+    double ph[kDecidePrefetch], cc[kDecidePrefetch], theta;
+};
+__device__ __forceinline__ void decide_prefetch(const FusedParams& p, int b, DecidePrefetch& d) {
+    int z = 0;
+    asm volatile("" : "+v"(z));   // vector loads: a scalarised s_load shares lgkmcnt with the LDS traffic of the caller's loop
+    const int n_dp = p.prefix ? p.stage_idx + 1 : p.L;
+    const bool dp = p.p_hist && (p.k_star || p.stop) && n_dp <= kDecidePrefetch;
+#pragma unroll
+    for (int i = 0; i < kDecidePrefetch; ++i) {
+        d.ph[i] = 0.0;
+        d.cc[i] = 0.0;
+        if (dp && i < n_dp) {
+            if (i != p.stage_idx) d.ph[i] = p.p_hist[static_cast<int64_t>(b) * p.L + i + z];
+            d.cc[i] = p.C[i + z];
+        }
+    }
+    d.theta = (p.theta && p.thr_stop) ? p.theta[p.stage_idx + z] : 0.0;
+}
+
 // lane-0 tail of the fused epilogue: Bayes adjustment, history update, DP rule, theta test
-__device__ __forceinline__ void decide_and_store(const FusedParams& p, int b, float sc) {
+template <bool PREFETCHED>
+__device__ __forceinline__ void decide_and_store_impl(const FusedParams& p, int b, float sc, const DecidePrefetch& d) {
     if (p.score) p.score[b] = sc;
     // pipeline.py:225-238: prob = predictor.predict(...); prob = bayesian_adjustment(prob, n_obs, a, b)
     double prob = static_cast<double>(sc);
@@ -124,9 +149,16 @@ __device__ __forceinline__ void decide_and_store(const FusedParams& p, int b, fl
         if (p.k_star || p.stop) {
             const int n_dp = p.prefix ? p.stage_idx + 1 : p.L;       // pipeline.py:248-256 uses the prefix
             double pp[ASD_MAX_STAGES], cc[ASD_MAX_STAGES], J[ASD_MAX_STAGES + 1];
+            if (PREFETCHED && n_dp <= kDecidePrefetch) {
 #pragma unroll
-            for (int i = 0; i < ASD_MAX_STAGES; ++i) {
-                if (i < n_dp) { pp[i] = (i == p.stage_idx) ? prob : ph[i]; cc[i] = p.C[i]; }
+                for (int i = 0; i < kDecidePrefetch; ++i) {
+                    if (i < n_dp) { pp[i] = (i == p.stage_idx) ? prob : d.ph[i]; cc[i] = d.cc[i]; }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < ASD_MAX_STAGES; ++i) {
+                    if (i < n_dp) { pp[i] = (i == p.stage_idx) ? prob : ph[i]; cc[i] = p.C[i]; }
+                }
             }
             const int ks = optimal_stopping1(pp, cc, p.lam, n_dp, 0, 1.0, 1.0, J);
             if (p.k_star) p.k_star[b] = ks;
@@ -135,8 +167,13 @@ __device__ __forceinline__ void decide_and_store(const FusedParams& p, int b, fl
     }
     if (p.theta && p.thr_stop) {
         const double q = static_cast<double>(sc);                    // minimal_adaptive_decoder.py:159-161
-        p.thr_stop[b] = (q >= p.theta[p.stage_idx] || p.stage_idx == p.L - 1) ? 1 : 0;
+        const double th = PREFETCHED ? d.theta : p.theta[p.stage_idx];
+        p.thr_stop[b] = (q >= th || p.stage_idx == p.L - 1) ? 1 : 0;
     }
+}
+__device__ __forceinline__ void decide_and_store(const FusedParams& p, int b, float sc) {
+    DecidePrefetch none;
+    decide_and_store_impl<false>(p, b, sc, none);
 }
 
 // ---- the reference's predictor (64 -> 32 -> 1), one wave per sequence ---------------------
@@ -145,6 +182,7 @@ __device__ __forceinline__ void decide_and_store(const FusedParams& p, int b, fl
 struct EpiPrefetch {
     float w[32];
     float b1, w2, b2, xv;
+    DecidePrefetch d;      // lane 0 only
 };
 
 __device__ __forceinline__ void epi_prefetch(const FusedParams& p, int b, int lane, EpiPrefetch& e) {
@@ -155,6 +193,7 @@ __device__ __forceinline__ void epi_prefetch(const FusedParams& p, int b, int la
     e.b1 = p.packed[64 * 32 + j];
     e.w2 = p.packed[64 * 32 + 32 + j];
     e.b2 = p.packed[64 * 32 + 64];
+    if (lane == 0) decide_prefetch(p, b, e.d);
 }
 
 // lpv: this lane's log-prob (lanes < n).  dvals: 3*64 doubles of LDS, xs: 64 floats of LDS (16-byte aligned).
@@ -192,7 +231,7 @@ __device__ __forceinline__ void epi_finish(const FusedParams& p, int b, int lane
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) z += __shfl_xor(z, off, 64);
     const float sc = 1.0f / (1.0f + expf(-(z + e.b2)));
-    if (lane == 0) decide_and_store(p, b, sc);
+    if (lane == 0) decide_and_store_impl<true>(p, b, sc, e.d);
 }
 
 }  // namespace asd

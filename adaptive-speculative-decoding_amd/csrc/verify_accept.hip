@@ -53,7 +53,7 @@ __device__ unsigned long long* g_asd_stamps = nullptr;
 #define ASD_STAMP_AT(slot)                                                                       \
     do {                                                                                         \
         if (threadIdx.x == 0 && g_asd_stamps)                                                    \
-            g_asd_stamps[static_cast<size_t>(blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+            g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define ASD_STAMP_AT(slot) do { } while (0)
@@ -141,18 +141,17 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     ASD_STAMP_AT(0);
 #ifdef ASD_STAMP
     if (threadIdx.x == 0 && g_asd_stamps)   // HW_REG_XCC_ID (id 20), all 32 bits
-        g_asd_stamps[static_cast<size_t>(blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
+        g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int S = a_S;
     const float c2 = a_scale2;
-    const int64_t bid = blockIdx.x;
-    const int row = static_cast<int>(bid / S);
-    const int split = static_cast<int>(bid - static_cast<int64_t>(row) * S);
-    const int b = row / a_K;
-    const int k = row - b * a_K;
+    // grid = (rows, splits): no division stands between the wave's start and its first loads (as a 1-D grid the prologue
+    // held three 64-bit and one 32-bit software divisions -- ~570 scalar instructions, ~2.8 us in the stamped build)
+    const int row = static_cast<int>(blockIdx.x);
+    const int split = static_cast<int>(blockIdx.y);
 
     const char* rowp = static_cast<const char*>(a_logits) + static_cast<int64_t>(row) * a_ld_row * E::kBytes;
     const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(rowp) & 15u);
@@ -161,8 +160,11 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     const int nvec = (a_V - head) / E::kPerVec;
     const int tail = a_V - head - nvec * E::kPerVec;
     const char* body = rowp + static_cast<int64_t>(head) * E::kBytes;
-    const int v0 = static_cast<int>(static_cast<int64_t>(nvec) * split / S);
-    const int v1 = static_cast<int>(static_cast<int64_t>(nvec) * (split + 1) / S);
+    int v0 = 0, v1 = nvec;
+    if (S > 1) {   // launcher: V * S < 2^31, so the products fit 32 bits
+        v0 = static_cast<int>(static_cast<uint32_t>(nvec) * static_cast<uint32_t>(split) / static_cast<uint32_t>(S));
+        v1 = static_cast<int>(static_cast<uint32_t>(nvec) * static_cast<uint32_t>(split + 1) / static_cast<uint32_t>(S));
+    }
 
     // the row's own scalars, fetched by lane 0 under the stream (one workgroup per row only).  Every one of these
     // small loads is ISSUED early and CONSUMED after the streaming loop (the compiler waits at the first use, and the
@@ -222,6 +224,8 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     const bool do_tail = wave == 0 && split == S - 1 && lane >= 32 && lane - 32 < tail;
     if (do_head) raw_head = E::raw(rowp, lane);
     if (do_tail) raw_tail = E::raw(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + (lane - 32));
+    const int b = static_cast<int>(static_cast<uint32_t>(row) / static_cast<uint32_t>(a_K));
+    const int k = row - b * a_K;
     EpiPrefetch pre;
     const bool fused = FUSED && own_row && p.mode == 0;
     if (FUSED) {
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     ASD_STAMP_AT(2);
 #ifdef ASD_STAMP
     if (lane == 0 && g_asd_stamps)   // per-wave stream end, after the per-workgroup records
-        g_asd_stamps[static_cast<size_t>(gridDim.x) * 8 + static_cast<size_t>(blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
+        g_asd_stamps[static_cast<size_t>(gridDim.x * gridDim.y) * 8 + static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (wave == 0) {
         // the small loads issued ahead of the loop are consumed here: head / tail elements -> slot n_tiles,
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             }
 #ifdef ASD_STAMP
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (g_asd_stamps) g_asd_stamps[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime() + (old & 0);
+            if (g_asd_stamps) g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime() + (old & 0);
 #endif
         }
         if (!fused) return;
@@ -506,10 +510,10 @@ inline int own_row_of(const VerifyParams& p) { return (p.S == 1 && (p.mode == 1 
 template <int DT, int THREADS, int UNROLL>
 void launch_nt(const VerifyParams& p, int64_t grid, hipStream_t st, int nt) {
     if (nt)
-        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, true, false>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st,
+        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, true, false>), dim3(static_cast<uint32_t>(grid / p.S), static_cast<uint32_t>(p.S)), dim3(THREADS), 0, st,
                            p.logits, p.tok, p.ld_row, p.V, p.K, p.S, p.scale2, own_row_of(p), p);
     else
-        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, false, false>), dim3(static_cast<uint32_t>(grid)), dim3(THREADS), 0, st,
+        hipLaunchKernelGGL((k_verify<DT, THREADS, UNROLL, false, false>), dim3(static_cast<uint32_t>(grid / p.S), static_cast<uint32_t>(p.S)), dim3(THREADS), 0, st,
                            p.logits, p.tok, p.ld_row, p.V, p.K, p.S, p.scale2, own_row_of(p), p);
 }
 
@@ -572,12 +576,12 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     p.region = static_cast<uint32_t>(region_bytes / sizeof(uint64_t));
 
     const int64_t grid = R * g.splits;
-    if (grid > INT32_MAX) return ASD_ERR_UNSUPPORTED;
+    if (grid > INT32_MAX || static_cast<int64_t>(p.V) * g.splits > INT32_MAX) return ASD_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
     if (p.row_entropy) {   // the (m2, s, t) instantiation exists for one workgroup per row, 512 lanes x 4-KiB tiles
         if (g.splits != 1 || g.threads != 512 || g.unroll != 4 || p.K > kFastMaxK || p.fused || p.mode != 0) return ASD_ERR_UNSUPPORTED;
-        const dim3 gd(static_cast<uint32_t>(grid));
+        const dim3 gd(static_cast<uint32_t>(grid / p.S), static_cast<uint32_t>(p.S));
 #define ASD_LAUNCH_STATS(DT)                                                                                      \
     hipLaunchKernelGGL((k_verify<DT, 512, 4, true, false, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row, p.V, \
                        p.K, p.S, p.scale2, own_row_of(p), p)
@@ -590,7 +594,7 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
         return launch_status();
     }
     if (p.fused) {   // the in-kernel epilogue is instantiated for the two geometries the heuristic uses when rows >= CUs
-        const dim3 gd(static_cast<uint32_t>(grid));
+        const dim3 gd(static_cast<uint32_t>(grid / p.S), static_cast<uint32_t>(p.S));
         const bool big = (g.threads == 1024 && g.unroll == 2);
         if (!big && !(g.threads == 512 && g.unroll == 4)) return ASD_ERR_UNSUPPORTED;
 #define ASD_LAUNCH_FUSED(DT)                                                                                      \
