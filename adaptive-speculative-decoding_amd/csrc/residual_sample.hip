@@ -108,8 +108,10 @@ __device__ __forceinline__ void accum_nucleus(const u32x4& v, float thr, float c
 }
 
 __device__ __forceinline__ void slice_tiles(int n_tiles, int s, int S, int& t0, int& t1) {
-    t0 = static_cast<int>(static_cast<int64_t>(n_tiles) * s / S);
-    t1 = static_cast<int>(static_cast<int64_t>(n_tiles) * (s + 1) / S);
+    // 32-bit: n_tiles * S < 2^31 for any row the launcher accepts (a 64-bit software division is ~150 scalar
+    // instructions in front of the first load of a latency-bound kernel)
+    t0 = static_cast<int>(static_cast<uint32_t>(n_tiles) * static_cast<uint32_t>(s) / static_cast<uint32_t>(S));
+    t1 = static_cast<int>(static_cast<uint32_t>(n_tiles) * static_cast<uint32_t>(s + 1) / static_cast<uint32_t>(S));
 }
 
 // ---- pass 1: per-slice (m2, s) of both rows -------------------------------------------------
@@ -161,18 +163,18 @@ __device__ __forceinline__ void row_norms(const RsParams& p, int b, float& Lt, f
 
 // weights of one 16-byte vector: w_i = max(0, p_t - p_d), and p_t itself; returns the lane's sums
 template <int DT>
-__device__ __forceinline__ void vector_weights(const u32x4& vt, const u32x4* vdp, float c2, float Lt, float Ld,
+__device__ __forceinline__ void vector_weights(const u32x4& vt, const u32x4& vd, bool has_d, float c2, float Lt, float Ld,
                                                float tthr, float dthr,
                                                float (&w)[Elem<DT>::kPerVec], float (&pt)[Elem<DT>::kPerVec]) {
     constexpr int N = Elem<DT>::kPerVec;
     float xt[N], xd[N];
     unpack<DT>(vt, xt);
-    if (vdp) unpack<DT>(*vdp, xd);
+    unpack<DT>(vd, xd);             // (by value, not through an optional pointer: that form went through scratch memory)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         // outside a row's nucleus the probability is exactly 0 (Lt / Ld are then the nucleus normalisers)
         pt[i] = xt[i] >= tthr ? fast_exp2(fmaf(xt[i], c2, -Lt)) : 0.0f;
-        const float pd = (vdp && xd[i] >= dthr) ? fast_exp2(fmaf(xd[i], c2, -Ld)) : 0.0f;
+        const float pd = (has_d && xd[i] >= dthr) ? fast_exp2(fmaf(xd[i], c2, -Ld)) : 0.0f;
         w[i] = fmaxf(pt[i] - pd, 0.0f);
     }
 }
@@ -197,9 +199,9 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_mass(const RsParams p) {
         if (rows.xt && v < p.nvec) {
             float w[N], pt[N];
             const u32x4 a = vt[v];
-            u32x4 d;
+            u32x4 d = {0u, 0u, 0u, 0u};
             if (vd) d = vd[v];
-            vector_weights<DT>(a, vd ? &d : nullptr, p.c2, Lt, Ld, rows.tthr, rows.dthr, w, pt);
+            vector_weights<DT>(a, d, vd != nullptr, p.c2, Lt, Ld, rows.tthr, rows.dthr, w, pt);
 #pragma unroll
             for (int i = 0; i < N; ++i) { z += w[i]; q += pt[i]; }
         }
@@ -291,9 +293,9 @@ __global__ __launch_bounds__(64) void k_rs_pick(const RsParams p) {
     for (int i = 0; i < N; ++i) { w[i] = 0.0f; pt[i] = 0.0f; }
     if (v < p.nvec) {
         const u32x4 a = vt[v];
-        u32x4 d;
+        u32x4 d = {0u, 0u, 0u, 0u};
         if (vd) d = vd[v];
-        vector_weights<DT>(a, vd ? &d : nullptr, p.c2, Lt, Ld, rows.tthr, rows.dthr, w, pt);
+        vector_weights<DT>(a, d, vd != nullptr, p.c2, Lt, Ld, rows.tthr, rows.dthr, w, pt);
     }
     double lm = 0.0;
 #pragma unroll
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_row(const DrParams p) {
             unpack<DT>(vec, x);
             if (thr != -INFINITY && !any_at_least(x, thr)) return;      // a tile without a survivor keeps mass 0
             float w[N], pt[N];
-            vector_weights<DT>(vec, nullptr, p.c2, Lt, 0.0f, thr, -INFINITY, w, pt);
+            vector_weights<DT>(vec, vec, false, p.c2, Lt, 0.0f, thr, -INFINITY, w, pt);
             float z = 0.0f;
 #pragma unroll
             for (int i = 0; i < N; ++i) z += pt[i];
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_row(const DrParams p) {
     float w[N], pt[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { w[i] = 0.0f; pt[i] = 0.0f; }
-    if (v < p.nvec) vector_weights<DT>(row[v], nullptr, p.c2, Lt, 0.0f, thr, -INFINITY, w, pt);
+    if (v < p.nvec) { const u32x4 q = row[v]; vector_weights<DT>(q, q, false, p.c2, Lt, 0.0f, thr, -INFINITY, w, pt); }
     double lm = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) lm += static_cast<double>(pt[i]);
