@@ -500,7 +500,7 @@ def main_lm_head(args):
                                    "cores": cores, "kind": "port",
                                    "sample": f"oracle.lm_head_verify (numpy f64 GEMM + f64 accept rule) on {vs} of {V} "
                                              f"vocabulary columns, {n} passes, scaled by V/{vs}"}
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if world > 1:
         dist.destroy_process_group()
 
@@ -583,16 +583,37 @@ def main_tiers(args):
                          "timing": "HIP events around 200 back-to-back verify launches on rank 0 after the loop (3 rotating buffers)"},
             "loop": rec,
         }
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
 
+_RESULT_FD = None
+
+
 def _quiet_rccl_banner():
-    """This image exports NCCL_DEBUG=VERSION, which makes RCCL print a version banner on STDOUT at communicator
-    creation -- in front of the one JSON line the driver parses.  Anything chattier than that is left alone."""
+    """The contract is ONE JSON line on stdout.  RCCL writes its version banner (this image exports NCCL_DEBUG=VERSION)
+    and every NCCL WARN (some boxes: 'Missing "iommu=pt"', 'Could not read node #') to the process's STDOUT at
+    communicator creation.  So file descriptor 1 is pointed at stderr for the whole run -- native libraries included --
+    and the result line goes to a private duplicate of the original stdout (_emit)."""
+    global _RESULT_FD
     if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
         os.environ["NCCL_DEBUG"] = "WARN"
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    """The one result line, to the real stdout."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_RESULT_FD, line)
 
 
 def sharded_verify_step(torch, dist, device, rank, world, B, K, V, D=8192, reps=30):
@@ -950,7 +971,7 @@ def main():
         def bail():
             if rank == 0 and state["out"] is not None:
                 state["out"]["sharded_verify"] = {"error": "timed out after 120 s"}
-                print(json.dumps(state["out"]), flush=True)
+                _emit(state["out"])
             os._exit(0)
         pending_watchdog = threading.Timer(120.0, bail)
         pending_watchdog.daemon = True
@@ -1013,7 +1034,7 @@ def main():
         if out is not None:
             out["sharded_verify"] = sharded_rec
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if distributed:
         dist.destroy_process_group()
 
