@@ -256,6 +256,14 @@ def test_row_parallel_paths_beyond_the_ballot_word(B, K, V):
     assert_verify_matches(run_gpu_verify(case), case["ref"])
 
 
+def test_more_rows_than_a_16_bit_grid_dimension():
+    """The launch grid is (rows, splits): rows = B*K = 72000 exceeds the 65535 limit of the y / z dimensions, so it must sit
+    in x; with explicit splits the same batch runs as 72000 x 2 workgroups through the ticket path."""
+    case = make_verify_case(9000, 8, 40, O.DT_BF16, seed=77)
+    assert_verify_matches(run_gpu_verify(case), case["ref"])
+    assert_verify_matches(run_gpu_verify(case, splits=2, threads=256, unroll=2, nontemporal=1), case["ref"])
+
+
 def test_lse_partial_row_parallel_form(K_):
     """asd_lse_partial where rows >= CUs (one workgroup per row writes its triple directly)."""
     import torch
