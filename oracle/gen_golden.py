@@ -334,6 +334,65 @@ def gen_logprob_idiom_full():
              temperature=np.float32(0.7), top_p=np.float32(0.9))
 
 
+NUCLEUS_SEED = 20251005
+
+
+def nucleus_row(seed: int, row: int, V: int, scale: float, storage: str) -> np.ndarray:
+    """The score row of the top-p goldens as f32 values (after the storage rounding), regenerated from (seed, row) by the
+    tests."""
+    x = (np.random.default_rng([seed, row]).standard_normal(V) * float(np.float32(scale))).astype(np.float32)   # (the fixture stores scale as f32)
+    if storage == "bf16":
+        x = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    elif storage == "f16":
+        x = x.astype(np.float16).astype(np.float32)
+    return x
+
+
+def gen_top_p_nucleus():
+    """X1: the proposal distribution the reference samples its training tokens from is HF generate()'s
+    (generate_training_data.py:110-119: do_sample, temperature=0.7, top_p=0.9), i.e. TemperatureLogitsWarper followed by
+    TopPLogitsWarper of the `transformers` package (requirements.txt: transformers>=4.40,<5; the classes of the installed
+    5.15.0 are used, their arithmetic -- ascending sort, f32 softmax + cumsum, remove cumulative <= 1 - top_p -- is
+    unchanged since 4.x).  Per row: the nucleus those two classes leave (size, smallest surviving raw score = the
+    threshold asd_draft_sample reports, number of scores EQUAL to the threshold that the warper removed -- its tie
+    handling follows the sort order, the kernel keeps every tie), the f64 log-sum-exp of the surviving scaled scores, and
+    how far top_p is from the two cumulative masses that bracket it (rows closer than 1e-5 are not compared exactly)."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopPLogitsWarper
+    cases = []
+    row = 0
+    for V in (1000, 32000, 152064):
+        for storage in ("f32", "bf16", "f16"):
+            for (T, top_p, scale) in ((0.7, 0.9, 3.0), (0.7, 0.9, 1.0), (1.0, 0.5, 4.0), (1.3, 0.95, 2.0), (0.5, 0.3, 6.0),
+                                      (0.7, 0.9, 0.05)):
+                cases.append((row, V, storage, T, top_p, scale))
+                row += 1
+    rec = {k: [] for k in ("row", "V", "storage", "T", "top_p", "scale", "n_keep", "thr", "ties_removed", "lse_keep",
+                           "margin")}
+    for (row, V, storage, T, top_p, scale) in cases:
+        x = nucleus_row(NUCLEUS_SEED, row, V, scale, storage)
+        score = torch.from_numpy(x.copy())[None, :]
+        score = TopPLogitsWarper(float(top_p))(None, TemperatureLogitsWarper(float(T))(None, score))
+        keep = torch.isfinite(score[0]).numpy()
+        thr = float(x[keep].min())
+        ties_removed = int(((x == np.float32(thr)) & ~keep).sum())
+        lse_keep = float(torch.logsumexp(score[0].double()[torch.from_numpy(keep)], dim=0))
+        # exact (f64) cumulative masses around the cut, for the comparison margin
+        z = np.sort(x.astype(np.float64) / np.float64(np.float32(T)))[::-1]
+        pr = np.exp(z - z[0])
+        pr /= pr.sum()
+        cum = np.cumsum(pr)
+        k = int(np.searchsorted(cum, np.float64(np.float32(top_p)), side="left"))
+        margin = float(min(abs(cum[min(k, V - 1)] - top_p), abs(cum[k - 1] - top_p) if k > 0 else 1.0))
+        for key, val in zip(rec, (row, V, storage, T, top_p, scale, int(keep.sum()), thr, ties_removed, lse_keep, margin)):
+            rec[key].append(val)
+    np.savez(os.path.join(OUT, "top_p_nucleus.npz"), seed=np.int64(NUCLEUS_SEED), row=np.array(rec["row"], np.int32),
+             V=np.array(rec["V"], np.int32), storage=np.array(rec["storage"]), T=np.array(rec["T"], np.float32),
+             top_p=np.array(rec["top_p"], np.float32), scale=np.array(rec["scale"], np.float32),
+             n_keep=np.array(rec["n_keep"], np.int64), thr=np.array(rec["thr"], np.float32),
+             ties_removed=np.array(rec["ties_removed"], np.int64), lse_keep=np.array(rec["lse_keep"], np.float64),
+             margin=np.array(rec["margin"], np.float64))
+
+
 def gen_dynamic_lambda():
     """DynamicCostOptimizer._optimize_lambda_parameter (src/serving/dynamic_cost_optimizer.py:425-487) called unbound
     on a stand-in `self` (the class constructor would start its background thread); the reference source runs
@@ -483,6 +542,7 @@ def main():
     gen_optimizer(dp, np.random.default_rng(4321))
     gen_logprob_idiom_full()
     gen_dynamic_lambda()
+    gen_top_p_nucleus()
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -152,8 +152,10 @@ def residual_sample(t_logits: np.ndarray, d_logits: np.ndarray, dtype: int, n_ac
 
 def draft_sample(logits: np.ndarray, dtype: int, r, B: int, V: int, inv_temperature: float = 1.0, top_p: float = 1.0,
                  ld_row: Optional[int] = None):
-    """asd_draft_sample in f64 (X1; no reference arithmetic -- HF generate with temperature / top_p at
-    generate_training_data.py:110-119 -- so PARITY UNPINNED).  logits: storage array [B, ld_row].
+    """asd_draft_sample in f64 (X1; the reference delegates it to HF generate with temperature / top_p,
+    generate_training_data.py:110-119: the truncated distribution is pinned to HF's TemperatureLogitsWarper +
+    TopPLogitsWarper by tests/golden/top_p_nucleus.npz, the draw -- inverse CDF in vocabulary order -- is this build's own
+    rule, PARITY UNPINNED).  logits: storage array [B, ld_row].
     Returns dict(tok i32[B], lp f64[B], thr f32[B] nucleus threshold logit (-inf = no truncation),
     margin_p f64[B] (distance of top_p to the bracketing cumulative masses), margin_r f64[B] (CDF-edge distance))."""
     lib = _load()

@@ -127,3 +127,32 @@ def full_size_cases(g):
             x = x.astype(np.float16).astype(np.float32)
         keep = g["keep"][int(g["keep_off"][i]):int(g["keep_off"][i + 1])] if var.endswith("_topp") else None
         yield var, int(g["tok"][i]), float(g["logprob"][i]), x, keep
+
+
+# ---- top-p goldens (tests/golden/top_p_nucleus.npz: HF TemperatureLogitsWarper + TopPLogitsWarper, oracle/gen_golden.py) ----
+def nucleus_cases(g):
+    """Yield dict(row, V, dtype, T, top_p, x (f32 values after the storage rounding), store (what the kernels read), n_keep,
+    thr, ties_removed, lse_keep, margin) for every row of the fixture; rows are regenerated from (seed, row)."""
+    seed = int(g["seed"])
+    dts = {"f32": O.DT_F32, "bf16": O.DT_BF16, "f16": O.DT_F16}
+    for i in range(g["row"].shape[0]):
+        V, storage = int(g["V"][i]), str(g["storage"][i])
+        x = (np.random.default_rng([seed, int(g["row"][i])]).standard_normal(V) * float(g["scale"][i])).astype(np.float32)
+        store = encode_logits(x[None, :], dts[storage])
+        yield dict(row=int(g["row"][i]), V=V, dtype=dts[storage], T=float(g["T"][i]), top_p=float(g["top_p"][i]),
+                   x=O.logits_as_f32(store, dts[storage])[0], store=store, n_keep=int(g["n_keep"][i]), thr=np.float32(g["thr"][i]),
+                   ties_removed=int(g["ties_removed"][i]), lse_keep=float(g["lse_keep"][i]), margin=float(g["margin"][i]))
+
+
+def check_nucleus_against_warper(c, tok, lp, thr, lp_atol):
+    """One draft-sampler result (token, log q(token), reported threshold) against the HF warper's nucleus of the row."""
+    x, T = c["x"], np.float32(c["T"])
+    if c["margin"] > 1e-5:                 # top_p is not within 1e-5 of a cumulative-mass step: the cut is unambiguous
+        assert np.float32(thr) == c["thr"], (c["row"], thr, c["thr"])
+        assert int((x >= thr).sum()) == c["n_keep"] + c["ties_removed"]       # the kernel keeps every tie, the warper's sort order decides
+    else:                                   # (f32 cumsum of the warper vs the exact masses): at most one step apart
+        assert abs(int((x >= thr).sum()) - c["n_keep"] - c["ties_removed"]) <= max(2, c["ties_removed"] + 2), c["row"]
+    assert x[tok] >= thr
+    if c["margin"] > 1e-5 and c["ties_removed"] == 0:
+        want = float(x[tok]) * float(np.float32(1.0) / T) - c["lse_keep"]      # log softmax(warped scores)[tok]
+        assert abs(lp - want) < lp_atol, (c["row"], lp, want)

@@ -2,9 +2,11 @@
 inverse-CDF draw, log q(tok)) and asd_residual_sample_ex (the residual against a nucleus-truncated draft row)
 against the f64 oracle.
 
-No reference arithmetic exists for this step: the reference calls HF `model.generate(do_sample=True,
-temperature=0.7, top_p=0.9)` (generate_training_data.py:110-119, third party) -> PARITY UNPINNED; what is pinned
-is the oracle's own definition (oracle/asd_oracle.c: nucleus_threshold, oracle_draft_sample).
+The reference delegates this step to HF `model.generate(do_sample=True, temperature=0.7, top_p=0.9)`
+(generate_training_data.py:110-119; transformers is third party for it).  The DISTRIBUTION is pinned to HF's own
+TemperatureLogitsWarper + TopPLogitsWarper (tests/golden/top_p_nucleus.npz, 54 rows; the oracle is checked against the
+same fixture on the CPU); the DRAW (torch.multinomial there, inverse CDF in vocabulary order here) is RNG-specific:
+parity unpinned for the token id, checked against the oracle's own definition (oracle/asd_oracle.c: oracle_draft_sample).
 Bars: the nucleus threshold is bit-exact where top_p sits >= 1e-5 of mass away from the two cumulative masses that
 bracket it; the token is bit-exact where, additionally, the draw is >= 1e-5 of mass away from a CDF edge; lp within
 1e-5 (BASELINE: fp32 scores within 1e-5)."""
@@ -100,6 +102,22 @@ def test_draft_sample_flat_and_peaked_rows_in_one_batch(K_, dtype):
         assert abs(lp[b] - lp_ref) < 2e-5
     tok2, lp2, thr2 = _gpu(K_, store, r, B, V, dtype, inv_t, 0.9)
     assert np.array_equal(tok, tok2) and np.array_equal(lp, lp2) and np.array_equal(thr, thr2)
+
+
+def test_draft_sample_reproduces_the_hf_warpers_nucleus(K_, golden):
+    """The kernel's nucleus against transformers' TemperatureLogitsWarper + TopPLogitsWarper (the proposal distribution of
+    the reference's generate() call, generate_training_data.py:110-119) on the 54 rows of tests/golden/top_p_nucleus.npz;
+    log q(token) against log softmax of the warped scores."""
+    from helpers import check_nucleus_against_warper, nucleus_cases
+    g = golden.npz("top_p_nucleus.npz")
+    n = 0
+    for c in nucleus_cases(g):
+        inv_t = float(np.float32(1.0) / np.float32(c["T"]))
+        for r0 in (0.37, 0.93):
+            tok, lp, thr = _gpu(K_, c["store"], np.array([r0], np.float32), 1, c["V"], c["dtype"], inv_t, c["top_p"])
+            check_nucleus_against_warper(c, int(tok[0]), float(lp[0]), thr[0], 2e-5)
+        n += 1
+    assert n == 54
 
 
 def test_draft_sample_strided_rows_ties_and_masked_logits(K_):

@@ -202,3 +202,19 @@ def test_logprob_idiom_at_full_vocabulary_with_temperature_and_top_p(golden):
         n += 1
     assert n == 30
     assert worst[True] <= 1e-6, worst         # nucleus rows: the idiom is exact to f32 rounding
+
+
+def test_draft_sample_oracle_reproduces_the_hf_warpers_nucleus(golden):
+    """X1: the oracle's top-p rule against transformers' TemperatureLogitsWarper + TopPLogitsWarper (what the reference's
+    generate(temperature=0.7, top_p=0.9) call applies, generate_training_data.py:110-119) on 54 rows: three vocabulary
+    sizes, three storage types, wide / tight / flat rows."""
+    from helpers import check_nucleus_against_warper, nucleus_cases
+    g = golden.npz("top_p_nucleus.npz")
+    n = 0
+    for c in nucleus_cases(g):
+        inv_t = float(np.float32(1.0) / np.float32(c["T"]))
+        r = np.array([0.37], np.float32)
+        ref = O.draft_sample(c["store"], c["dtype"], r, 1, c["V"], inv_t, c["top_p"])
+        check_nucleus_against_warper(c, int(ref["tok"][0]), float(ref["lp"][0]), ref["thr"][0], 2e-6)
+        n += 1
+    assert n == 54
