@@ -393,6 +393,102 @@ def gen_top_p_nucleus():
              margin=np.array(rec["margin"], np.float64))
 
 
+SPEC_SEED = 20251006
+
+
+def spec_case_inputs(seed: int, case: int, K: int, V: int, scale: float, spread: float):
+    """Draft logits [K, V], target logits [K + 1, V] (f32), the drafted tokens (inverse CDF of the draft row against a stored
+    uniform) -- regenerated from (seed, case) by the tests."""
+    rng = np.random.default_rng([seed, case])
+    cand = (rng.standard_normal((K, V)) * float(np.float32(scale))).astype(np.float32)
+    new = np.empty((K + 1, V), np.float32)
+    new[:K] = (cand.astype(np.float64) + rng.standard_normal((K, V)) * float(np.float32(spread))).astype(np.float32)
+    new[K] = (rng.standard_normal(V) * float(np.float32(scale))).astype(np.float32)
+    pick = rng.uniform(0, 1, K)
+    ids = np.empty(K, np.int64)
+    for k in range(K):
+        z = cand[k].astype(np.float64)
+        q = np.exp(z - z.max())
+        q /= q.sum()
+        ids[k] = min(int(np.searchsorted(np.cumsum(q), pick[k], side="right")), V - 1)
+    return cand, new, ids
+
+
+def gen_speculative_sampling():
+    """A5 + the residual draw against transformers' `_speculative_sampling` (generation/utils.py; algorithm 1 of the
+    speculative-decoding paper as HF's assisted generation runs it -- the reference itself has no token-level accept test,
+    SURVEY F2).  The function is called unmodified; its two random draws are made deterministic from outside:
+    `torch.rand_like` returns the fixture's uniforms (r_i, the acceptance test `r_i <= p_i / q_i`), `torch.multinomial`
+    records the distribution it is asked to sample from (p' = norm(max(0, p - q)), or p_{n+1} when every draft was
+    accepted).  Stored per case: the uniforms, HF's n_matches, and for three uniforms r the token the inverse CDF (in
+    vocabulary order, this build's draw rule) selects from HF's p' -- with the distance of r to the nearer CDF edge, so that
+    draws an f32 softmax cannot decide are not compared."""
+    import transformers.generation.utils as U
+    cases = []
+    c = 0
+    for V in (1000, 32000):
+        for K in (4, 8):
+            for scale, spread in ((3.0, 0.5), (4.0, 1.5), (2.0, 0.1)):
+                for rep in range(2):
+                    cases.append((c, K, V, scale, spread))
+                    c += 1
+    rec = dict(case=[], K=[], V=[], scale=[], spread=[], u=[], u_off=[0], n_matches=[], r=[], tok=[], margin=[])
+    rng = np.random.default_rng(SPEC_SEED)
+    real_rand_like, real_multinomial = torch.rand_like, torch.multinomial
+    for (case, K, V, scale, spread) in cases:
+        cand, new, ids = spec_case_inputs(SPEC_SEED, case, K, V, scale, spread)
+        # uniforms away from the decision edge (|log u - log(p_i / q_i)| >= 1e-3), as the parity set of A5 requires
+        lq = cand.astype(np.float64) - np.log(np.exp(cand.astype(np.float64) - cand.max(1, keepdims=True)).sum(1, keepdims=True)) - cand.max(1, keepdims=True)
+        lp = new[:K].astype(np.float64) - np.log(np.exp(new[:K].astype(np.float64) - new[:K].max(1, keepdims=True)).sum(1, keepdims=True)) - new[:K].max(1, keepdims=True)
+        ratio = (lp - lq)[np.arange(K), ids]
+        u = rng.uniform(0, 1, K)
+        for _ in range(100):
+            bad = np.abs(np.log(u) - ratio) < 1e-3
+            if not bad.any():
+                break
+            u[bad] = rng.uniform(0, 1, int(bad.sum()))
+        u = u.astype(np.float32)
+        got = {}
+
+        def fake_rand_like(t, *a, **k):
+            return torch.from_numpy(u.copy()).to(t.dtype).reshape(t.shape)
+
+        def fake_multinomial(p, num_samples=1, **k):
+            got["p"] = p.detach().clone()
+            return torch.zeros((p.shape[0], num_samples), dtype=torch.long)
+
+        torch.rand_like, torch.multinomial = fake_rand_like, fake_multinomial
+        try:
+            _, n = U._speculative_sampling(torch.from_numpy(ids)[None, :], torch.from_numpy(cand)[None], K,
+                                           torch.from_numpy(new)[None], False)
+        finally:
+            torch.rand_like, torch.multinomial = real_rand_like, real_multinomial
+        n = int(n)
+        pp = got["p"][0].double().numpy()
+        cum = np.cumsum(pp)
+        total = cum[-1]
+        rs = rng.uniform(0, 1, 3).astype(np.float32)
+        for r in rs:
+            target = float(r) * total
+            t = int(np.searchsorted(cum, target, side="right"))
+            while t < V - 1 and pp[t] <= 0.0:
+                t += 1
+            t = min(t, V - 1)
+            lo = cum[t - 1] if t > 0 else 0.0
+            rec["r"].append(r)
+            rec["tok"].append(t)
+            rec["margin"].append(min(target - lo, cum[t] - target) / total)
+        rec["case"].append(case); rec["K"].append(K); rec["V"].append(V); rec["scale"].append(scale)
+        rec["spread"].append(spread); rec["u"].append(u); rec["u_off"].append(rec["u_off"][-1] + K)
+        rec["n_matches"].append(n)
+    np.savez(os.path.join(OUT, "speculative_sampling.npz"), seed=np.int64(SPEC_SEED), case=np.array(rec["case"], np.int32),
+             K=np.array(rec["K"], np.int32), V=np.array(rec["V"], np.int32), scale=np.array(rec["scale"], np.float32),
+             spread=np.array(rec["spread"], np.float32), u=np.concatenate(rec["u"]).astype(np.float32),
+             u_off=np.array(rec["u_off"], np.int64), n_matches=np.array(rec["n_matches"], np.int32),
+             r=np.array(rec["r"], np.float32).reshape(-1, 3), tok=np.array(rec["tok"], np.int32).reshape(-1, 3),
+             margin=np.array(rec["margin"], np.float64).reshape(-1, 3))
+
+
 def gen_dynamic_lambda():
     """DynamicCostOptimizer._optimize_lambda_parameter (src/serving/dynamic_cost_optimizer.py:425-487) called unbound
     on a stand-in `self` (the class constructor would start its background thread); the reference source runs
@@ -543,6 +639,7 @@ def main():
     gen_logprob_idiom_full()
     gen_dynamic_lambda()
     gen_top_p_nucleus()
+    gen_speculative_sampling()
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -156,3 +156,29 @@ def check_nucleus_against_warper(c, tok, lp, thr, lp_atol):
     if c["margin"] > 1e-5 and c["ties_removed"] == 0:
         want = float(x[tok]) * float(np.float32(1.0) / T) - c["lse_keep"]      # log softmax(warped scores)[tok]
         assert abs(lp - want) < lp_atol, (c["row"], lp, want)
+
+
+# ---- A5 + residual goldens (tests/golden/speculative_sampling.npz: transformers' _speculative_sampling) ------------------
+def spec_cases(g):
+    """Yield the verify / residual inputs of every fixture case, regenerated from (seed, case) exactly as
+    oracle/gen_golden.py::spec_case_inputs drew them, with HF's n_matches and the inverse-CDF tokens of its p'."""
+    seed = int(g["seed"])
+    for i in range(g["case"].shape[0]):
+        K, V = int(g["K"][i]), int(g["V"][i])
+        rng = np.random.default_rng([seed, int(g["case"][i])])
+        cand = (rng.standard_normal((K, V)) * float(g["scale"][i])).astype(np.float32)
+        new = np.empty((K + 1, V), np.float32)
+        new[:K] = (cand.astype(np.float64) + rng.standard_normal((K, V)) * float(g["spread"][i])).astype(np.float32)
+        new[K] = (rng.standard_normal(V) * float(g["scale"][i])).astype(np.float32)
+        pick = rng.uniform(0, 1, K)
+        ids = np.empty(K, np.int32)
+        lq = np.empty(K)
+        for k in range(K):
+            z = cand[k].astype(np.float64)
+            q = np.exp(z - z.max())
+            q /= q.sum()
+            ids[k] = min(int(np.searchsorted(np.cumsum(q), pick[k], side="right")), V - 1)
+            lq[k] = np.log(q[ids[k]])
+        u = g["u"][int(g["u_off"][i]):int(g["u_off"][i + 1])].astype(np.float32)
+        yield dict(K=K, V=V, cand=cand, new=new, tok=ids, lp_d=lq.astype(np.float32), u=u, n_matches=int(g["n_matches"][i]),
+                   r=g["r"][i].astype(np.float32), want_tok=g["tok"][i].astype(np.int32), margin=g["margin"][i])

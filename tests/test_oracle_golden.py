@@ -218,3 +218,25 @@ def test_draft_sample_oracle_reproduces_the_hf_warpers_nucleus(golden):
         check_nucleus_against_warper(c, int(ref["tok"][0]), float(ref["lp"][0]), ref["thr"][0], 2e-6)
         n += 1
     assert n == 54
+
+
+def test_accept_rule_and_residual_distribution_against_hf_speculative_sampling(golden):
+    """A5 + the residual draw: the oracle against transformers' `_speculative_sampling` (assisted generation; algorithm 1 of
+    the speculative-decoding paper) called unmodified with its uniforms supplied from outside: same number of accepted
+    drafts on all 24 cases (n_matches 0 .. K), and the inverse CDF of HF's residual distribution p' = norm(max(0, p - q))
+    (or of p_{n+1} after a fully accepted block) picks the token the oracle picks wherever the draw is >= 1e-5 of the
+    mass away from a CDF edge."""
+    from helpers import spec_cases
+    g = golden.npz("speculative_sampling.npz")
+    n_cases = n_draws = 0
+    for c in spec_cases(g):
+        K, V = c["K"], c["V"]
+        ref = O.verify_accept(c["new"][:K], O.DT_F32, c["tok"], c["lp_d"], c["u"], 1, K, V)
+        assert int(ref["n_acc"][0]) == c["n_matches"]
+        for r, want, margin in zip(c["r"], c["want_tok"], c["margin"]):
+            tok, _ = O.residual_sample(c["new"][:K], c["cand"], O.DT_F32, [c["n_matches"]], [r], 1, K, V, bonus=c["new"][K:K + 1])
+            if margin > 1e-5:
+                assert int(tok[0]) == int(want)
+                n_draws += 1
+        n_cases += 1
+    assert n_cases == 24 and n_draws >= 60
