@@ -475,7 +475,41 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_row(const DrParams p) {
 
     float m2, s;
     ASD_DR_STAMP(0);
-    block_lse(m2, s);
+    // Without truncation the first sweep also leaves every tile's OWN (max, sum) pair in LDS: the tile masses then follow
+    // from L without a second exp-per-element sweep of the row (24 -> 15 us at B <= 32).
+    const bool tiles_from_sweep1 = p.levels == 0;
+    if (tiles_from_sweep1) {
+        for_each([&](int v, const u32x4& vec) {
+            float x[N];
+            unpack<DT>(vec, x);
+            float vmax = x[0];
+#pragma unroll
+            for (int i = 1; i < N; ++i) vmax = fmaxf(vmax, x[i]);
+            const float ml = fmaxf(vmax * p.c2, kSentinel);   // a lane of -inf logits: finite sentinel, every term 0
+            float sl = 0.0f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) sl += fast_exp2(fmaf(x[i], p.c2, -ml));
+            const float M = wave_max(ml);
+            const float sw = wave_sum(sl * fast_exp2(ml - M));
+            if (lane == 0) {                                  // nothing is carried from tile to tile: the four tiles of a
+                tile_span[v >> 6] = __float_as_uint(M);       // for_each step reduce side by side
+                tile_mass[v >> 6] = sw;
+            }
+        });
+        // the wave's pair from its own tiles (wave + 16 j), one per lane, in a fixed order
+        float wm = kSentinel, ws = 0.0f;
+        for (int tile = wave + kDrWaves * lane; tile < p.n_tiles; tile += kDrWaves * 64)
+            ms_merge(wm, ws, __uint_as_float(tile_span[tile]), tile_mass[tile]);
+        wave_merge(wm, ws);
+        if (lane == 0) { red[wave][0] = wm; red[wave][1] = ws; }
+        __syncthreads();
+        m2 = red[0][0];
+        s = red[0][1];
+#pragma unroll
+        for (int w = 1; w < kDrWaves; ++w) ms_merge(m2, s, red[w][0], red[w][1]);
+    } else {
+        block_lse(m2, s);
+    }
     ASD_DR_STAMP(1);
     double L64 = static_cast<double>(m2) + log2_split(s);      // log2 of the normaliser of the distribution drawn from
     float thr = -INFINITY;
@@ -644,6 +678,9 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_row(const DrParams p) {
             for (int e = first; e < last; ++e) z += __uint_as_float(cand[wave][e]);
             tile_mass[tile] = z;
         }
+    } else if (tiles_from_sweep1) {
+        for (int i = t; i < p.n_tiles; i += kDrThreads)       // (written before the barrier inside the first sweep's combine)
+            tile_mass[i] *= fast_exp2(__uint_as_float(tile_span[i]) - Lt);
     } else {
         for (int i = t; i < p.n_tiles; i += kDrThreads) tile_mass[i] = 0.0f;
         __syncthreads();
