@@ -30,7 +30,21 @@ __global__ __launch_bounds__(256, 1) void k_gemm4(const uint16_t* __restrict__ W
     const int wm = wv & 1, wn = wv >> 1;
     const int r = lane & 31, h = lane >> 5;
     const int n_blocks = N / kTile;
-    const int nb = blockIdx.x % n_blocks, mb = blockIdx.x / n_blocks;
+    // the row blocks that share a weight tile get ids 8 apart: the same XCD (round-robin dispatch) and the same dispatch round,
+    // so one of them pulls the tile from HBM and the others find it in that XCD's L2 (as the shipped kernel does)
+    const int m_blocks = M / kTile;
+    int nb, mb;
+    {
+        const int id = blockIdx.x, group = 8 * m_blocks, swizzled = (n_blocks / 8) * group;
+        if (id < swizzled) {
+            const int in_group = id % group;
+            nb = (id / group) * 8 + in_group % 8;
+            mb = in_group / 8;
+        } else {
+            mb = (id - swizzled) % m_blocks;
+            nb = (n_blocks / 8) * 8 + (id - swizzled) / m_blocks;
+        }
+    }
     const char* wbase = reinterpret_cast<const char*>(W) + static_cast<int64_t>(nb) * kTile * D * 2;
     const char* hbase = reinterpret_cast<const char*>(H) + static_cast<int64_t>(mb) * kTile * D * 2;
     // staging: piece id = ps * 256 + t -> row id >> 3, 16-byte segment id & 7; LDS image XOR-swizzled like the shipped kernel
@@ -86,6 +100,42 @@ __global__ __launch_bounds__(256, 1) void k_gemm4(const uint16_t* __restrict__ W
             for (int nt = 0; nt < 4; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], hf[set][mt], acc[mt][nt], 0, 0, 0);
     };
+    // One scheduling region per k-step: 16 MFMAs with the 8 fragment reads of the NEXT k-step, 4 staging stores and 4 staging
+    // loads dealt between them (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read), so that the
+    // wave never issues a long run of non-MFMA instructions while the matrix pipe drains.
+    auto interleave = [&](bool reads, bool stores, bool loads) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (stores) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (loads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // 16 MFMAs with 8 fragment reads, 8 staging stores and 8 staging loads
+    auto interleave2 = [&](bool stores, bool loads) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (stores) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (loads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     const int n_super = D / kSuper;
     // a quarter of the staging work -- 4 of the 16 register pieces: ds_write of stage S + 1, then the load of stage S + 2 into
     // the same registers -- behind each of the four MFMA groups of superstage S
@@ -106,30 +156,39 @@ __global__ __launch_bounds__(256, 1) void k_gemm4(const uint16_t* __restrict__ W
             }
         }
     };
-    auto superstage = [&](int S, bool store, bool load) {
+    // The LAST k-step of a superstage is multiplied behind the barrier that ends it (its fragments are in register set 1 by
+    // then), together with the reads of the next superstage's first k-step: the matrix pipe has 16 MFMAs of work while the
+    // first fragments of the new buffer arrive.
+    auto superstage = [&](int S, bool first, bool store, bool load) {
         const int buf = S & 1;
         read_frags(buf, 0, 0);
+        if (!first) multiply(1);                       // (S - 1, k-step 3)
+        restage(S, 0, store, load);
+        interleave(true, store, load);
         read_frags(buf, 1, 1);
         multiply(0);
-        restage(S, 0, store, load);
+        restage(S, 1, store, load);
+        interleave(true, store, load);
         read_frags(buf, 2, 0);
         multiply(1);
-        restage(S, 1, store, load);
+        restage(S, 2, store, load);
+        interleave(true, store, load);
         read_frags(buf, 3, 1);
         multiply(0);
-        restage(S, 2, store, load);
-        multiply(1);
         restage(S, 3, store, load);
+        interleave(true, store, load);
         __syncthreads();
     };
     load_stage(0);
     store_stage(0);
     __syncthreads();
-    load_stage(1);                       // (n_super >= 2 in every run below)
-    int S = 0;
-    for (; S + 2 < n_super; ++S) superstage(S, true, true);
-    superstage(S, true, false);
-    superstage(S + 1, false, false);
+    load_stage(1);                       // (n_super >= 3 in every run below)
+    superstage(0, true, true, true);
+    int S = 1;
+    for (; S + 2 < n_super; ++S) superstage(S, false, true, true);
+    superstage(S, false, true, false);
+    superstage(S + 1, false, false, false);
+    multiply(1);
     float sum = 0.0f;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -168,7 +227,12 @@ int main() {
         const int probe = grid - 3;
         std::vector<float> got(256);
         CHECK(hipMemcpy(got.data(), sink + static_cast<size_t>(probe) * 256, 1024, hipMemcpyDeviceToHost));
-        const int nbk = probe % (N / 256), mbk = probe / (N / 256);
+        int nbk, mbk;
+        {
+            const int n_blocks = N / 256, m_blocks = M / 256, group = 8 * m_blocks, swizzled = (n_blocks / 8) * group;
+            if (probe < swizzled) { const int in_group = probe % group; nbk = (probe / group) * 8 + in_group % 8; mbk = in_group / 8; }
+            else { mbk = (probe - swizzled) % m_blocks; nbk = (n_blocks / 8) * 8 + (probe - swizzled) / m_blocks; }
+        }
         double worst = 0.0;
         for (int t = 0; t < 256; ++t) {
             const int lane = t & 63, wv = t >> 6, wm = wv & 1, wn = wv >> 1, r = lane & 31, h = lane >> 5;
