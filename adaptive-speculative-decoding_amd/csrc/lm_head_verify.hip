@@ -66,6 +66,7 @@ struct LmHeadParams {
     int col0;            // first vocabulary column of this launch
     int unit0;           // index of this launch's first block in msg (one record per row and block)
     int packed;          // != 0: `weight` is the tile-major image of asd_lm_head_pack_weights ([V/256][D/64][256 rows][64 cols])
+    int need_argmax;     // the caller wants the row arg-max (argmax_out / greedy): otherwise the epilogue skips its bookkeeping
     int k_slices;        // > 1: every column block is cut into this many reduction slices (one workgroup each)
     float* slabs;        // [n_blocks][k_slices][8 waves][2 * NTW * 4][64 lanes] float4: partial accumulators
     uint32_t* tickets;   // [n_blocks], zero before the launch; the slice that draws k_slices - 1 finishes the block
@@ -76,6 +77,34 @@ __device__ __forceinline__ void wait_and_meet() {
     // lgkmcnt(0): this wave's LDS reads (the fragments it carries across the barrier) have returned, so the
     // slots it read may be refilled by anyone once the barrier is passed
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PENDING) : "memory");
+}
+
+// One 32 x 32 accumulator tile of a lane -- 16 vocabulary entries n = n_first + (i & 3) + 8 * (i >> 2) of ONE row -- folded
+// into the row's running (m2, s), the drafted token's logit g and, if wanted, the arg-max (value, id; ties -> lowest id, NaN
+// never wins, padding never wins a tie at -inf).  Selects, not branches: as short-circuit `if`s this was ~35 instructions and
+// two exec-mask branches per logit -- 17 us per 256 x 256 block, 6-15 % of a block's time.
+template <bool ARGMAX>
+__device__ __forceinline__ void fold_tile16(const f32x16& a, int n_first, int tk, int V, float c2, float& m2, float& s, float& g,
+                                            float& bv, int& bi) {
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = n_first + (i & 3) + 8 * (i >> 2);
+        const bool valid = n < V;
+        const float v = valid ? a[i] : -INFINITY;            // padded weight rows are not vocabulary
+        g = (n == tk) ? v : g;
+        if (ARGMAX) {
+            const bool better = (v > bv) | ((v == bv) & (n < bi) & valid);
+            bv = better ? v : bv;
+            bi = better ? n : bi;
+        }
+        x[i] = v;
+    }
+    float lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { lo[i] = x[i]; hi[i] = x[8 + i]; }
+    accum8(lo, c2, m2, s);
+    accum8(hi, c2, m2, s);
 }
 
 // NTW: 32-column accumulator tiles per wave: 4 (256-column block) or 2 (128-column block).
@@ -359,20 +388,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         if (wave_works) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                float x[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int n = n0 + 32 * NTW * wn + 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const float v = n < p.V ? acc[mt][nt][i] : -INFINITY;   // padded weight rows are not vocabulary
-                    if (n == tk) g = v;
-                    if (v > bv || (v == bv && n < bi && n < p.V)) { bv = v; bi = n; }   // padding never wins a tie at -inf
-                    x[i] = v;
-                }
-                float lo[8], hi[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { lo[i] = x[i]; hi[i] = x[8 + i]; }
-                accum8(lo, p.c2, m2, s);
-                accum8(hi, p.c2, m2, s);
+                const int n_first = n0 + 32 * NTW * wn + 32 * nt + 4 * h;
+                if (p.need_argmax) fold_tile16<true>(acc[mt][nt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
+                else fold_tile16<false>(acc[mt][nt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
             }
         }
         // the row's other columns of these tiles sit in lane r ^ 32
@@ -397,6 +415,235 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         const int m = m0 + 64 * wm + 32 * mt + r;
         if (m >= p.M) continue;
         const float* q = meet + (64 * wm + 32 * mt + r) * kMsg;
+        float m2 = tm2[mt], s = ts[mt], g = tg[mt], bv = tbv[mt];
+        int bi = tbi[mt];
+        ms_merge(m2, s, q[0], q[1]);
+        const float go = q[2];
+        g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));
+        const float bvo = q[3];
+        const int bio = __float_as_int(q[4]);
+        if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+        float* out = p.msg + (static_cast<int64_t>(p.unit0 + nb) * p.M + m) * kMsg;
+        out[0] = m2;
+        out[1] = s;
+        out[2] = g;
+        out[3] = bv;
+        out[4] = __int_as_float(bi);
+    }
+}
+
+// ---- M > 256 rows (several row blocks share every weight tile): FOUR waves per workgroup, 128 x 128 logits per wave.
+// With the weights re-read from L2 by the row blocks of a tile the call is MFMA-bound, and the 8-wave kernel above spends
+// its issue slots on fragment reads: 6 ds_read_b128 per 8 MFMAs and wave, two waves per SIMD taking turns, 0.94-0.97 PF.
+// Here a wave owns 16 accumulator tiles (256 AGPRs; 16 MFMAs per 8 fragment reads), the operands are staged
+// global -> VGPR -> ds_write_b128 into a double-buffered XOR-swizzled LDS image (plain loads and stores: the compiler counts
+// vmcnt / lgkmcnt itself -- the steady state is branch-free so that it CAN count), and every k-step is ONE scheduling region
+// in which sched_group_barrier deals the 8 fragment reads of the next k-step, 4 staging stores and 4 staging loads between
+// the 16 MFMAs, so the wave never issues a long run of non-MFMA instructions while the matrix pipe drains.  The last k-step
+// of a superstage is multiplied behind the barrier that ends it, over the first fragment reads of the next one.
+// tools/lab_gemm4.hip is this loop as a stand-alone program (profiles/r02_lab_gemm4.txt: 0.92 PF without the pinned
+// read-ahead, 1.00 with it, 1.09 with the interleave, 1.25 with the XCD-aware block order -- the library GEMM's rate).
+constexpr int kQThreads = 256;
+
+__global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
+    constexpr int kSlot = kBM * 128;          // one operand, one superstage: 256 rows x 128 bytes
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * kSlot];     // [buffer][weights | hidden]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv & 1, wn = wv >> 1;
+    const int r = lane & 31, h = lane >> 5;
+    int mb, nb;
+    {   // the row blocks that share a weight tile get ids 8 apart: one XCD, one dispatch round (see k_lm_head_tile)
+        const int id = static_cast<int>(blockIdx.x);
+        const int group = 8 * p.m_blocks;
+        const int swizzled = (p.n_blocks / 8) * group;
+        if (id < swizzled) {
+            const int in_group = id % group;
+            nb = (id / group) * 8 + in_group % 8;
+            mb = in_group / 8;
+        } else {
+            mb = (id - swizzled) % p.m_blocks;
+            nb = (p.n_blocks / 8) * 8 + (id - swizzled) / p.m_blocks;
+        }
+    }
+    const int n0 = p.col0 + nb * 256, m0 = mb * kBM;
+    const int rows_w = min(256, p.V - n0), rows_h = min(kBM, p.M - m0);
+    const int64_t w_stage_stride = p.packed ? 256 * 128 : kSuper * 2;
+    const uint32_t w_row_stride = p.packed ? 128u : static_cast<uint32_t>(p.ld_w * 2);
+    const char* const wbase = p.packed
+        ? static_cast<const char*>(p.weight) + (static_cast<int64_t>(n0 / 256) * (p.D / kSuper)) * (256 * 128)
+        : static_cast<const char*>(p.weight) + static_cast<int64_t>(n0) * p.ld_w * 2;
+    const char* const hbase = static_cast<const char*>(p.hidden) + static_cast<int64_t>(m0) * p.ld_h * 2;
+    // staging piece ps * 256 + t: row id >> 3, 16-byte segment id & 7.  Rows past a matrix edge re-read the last valid row
+    // (their products are masked in the epilogue): no lane addresses outside the operands.
+    uint32_t woff[8], hoff[8], loff[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int id = ps * 256 + t;
+        const int row = id >> 3, seg = id & 7;
+        woff[ps] = static_cast<uint32_t>(min(row, rows_w - 1)) * w_row_stride + seg * 16;
+        hoff[ps] = static_cast<uint32_t>(min(row, rows_h - 1)) * static_cast<uint32_t>(p.ld_h * 2) + seg * 16;
+        loff[ps] = row * 128 + ((seg ^ ((row >> 1) & 7)) * 16);
+    }
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v sw[8], sh[8];
+    const int n_super = p.D / kSuper;
+    auto load_piece = [&](int S, int ps) {
+        sw[ps] = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(wbase + static_cast<int64_t>(S) * w_stage_stride + woff[ps]));
+        sh[ps] = *reinterpret_cast<const u32x4v*>(hbase + static_cast<int64_t>(S) * (kSuper * 2) + hoff[ps]);
+    };
+    auto store_piece = [&](int buf, int ps) {
+        unsigned char* wb = lds + buf * 2 * kSlot;
+        *reinterpret_cast<u32x4v*>(wb + loff[ps]) = sw[ps];
+        *reinterpret_cast<u32x4v*>(wb + kSlot + loff[ps]) = sh[ps];
+    };
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
+    // wave-uniform (made scalar: a uniform jump, not an exec mask around the k-steps): a wave of padding only stages
+    const bool wave_works = __builtin_amdgcn_readfirstlane((128 * wm < rows_h && 128 * wn < rows_w) ? 1 : 0) != 0;
+    const int key = (r >> 1) & 7;
+    const int w_off = (128 * wn + r) * 128, h_off = (128 * wm + r) * 128;
+    bf16x8 wf[2][4], hf[2][4];
+    auto read_frags = [&](int buf, int ks, int set) {
+        const unsigned char* wb = lds + buf * 2 * kSlot + w_off;
+        const unsigned char* hb = lds + buf * 2 * kSlot + kSlot + h_off;
+        const int so = ((4 * h + ks) ^ key) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf[set][i] = *reinterpret_cast<const bf16x8*>(wb + i * 32 * 128 + so);
+            hf[set][i] = *reinterpret_cast<const bf16x8*>(hb + i * 32 * 128 + so);
+        }
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], hf[set][mt], acc[mt][nt], 0, 0, 0);
+    };
+    // one scheduling region: 16 MFMAs, 8 DS reads, 4 DS writes, 4 VMEM reads (masks 0x008 / 0x100 / 0x200 / 0x020)
+    auto interleave = [&](bool stores, bool loads) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (stores) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (loads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // a quarter of the staging: two pieces of stage S + 1 go to the other LDS buffer, the same registers take stage S + 2
+    auto restage = [&](int S, int part, bool store, bool load) {
+#pragma unroll
+        for (int ps = 2 * part; ps < 2 * part + 2; ++ps) {
+            if (store) store_piece((S + 1) & 1, ps);
+            if (load) load_piece(S + 2, ps);
+        }
+    };
+    // `first` / `store` / `load` are compile-time constants at every call: the loop below is branch-free in steady state.
+    // (A wave of padding rows / columns only stages; the test is hoisted so that a working wave's k-step -- reads, MFMAs,
+    // staging -- stays ONE basic block, which is what sched_group_barrier orders.)
+    auto superstage = [&](int S, bool first, bool store, bool load) {
+        const int buf = S & 1;
+        if (wave_works) {
+            read_frags(buf, 0, 0);
+            if (!first) multiply(1);                   // (S - 1, k-step 3): its fragments were read before the barrier
+            restage(S, 0, store, load);
+            interleave(store, load);
+            read_frags(buf, 1, 1);
+            multiply(0);
+            restage(S, 1, store, load);
+            interleave(store, load);
+            read_frags(buf, 2, 0);
+            multiply(1);
+            restage(S, 2, store, load);
+            interleave(store, load);
+            read_frags(buf, 3, 1);
+            multiply(0);
+            restage(S, 3, store, load);
+            interleave(store, load);
+        } else {
+#pragma unroll
+            for (int part = 0; part < 4; ++part) restage(S, part, store, load);
+        }
+        __syncthreads();
+    };
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) load_piece(0, ps);
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) store_piece(0, ps);
+    __syncthreads();
+    if (n_super >= 3) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) load_piece(1, ps);
+        superstage(0, true, true, true);
+        int S = 1;
+        for (; S + 2 < n_super; ++S) superstage(S, false, true, true);
+        superstage(S, false, true, false);
+        superstage(S + 1, false, false, false);
+    } else if (n_super == 2) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) load_piece(1, ps);
+        superstage(0, true, true, false);
+        superstage(1, false, false, false);
+    } else {
+        superstage(0, true, false, false);
+    }
+    if (wave_works) multiply(1);                       // k-step 3 of the last superstage
+
+    // ---- epilogue (as k_lm_head_tile): D[vocab row][m column]; lane (r, h) holds row m of four 32-row tiles and, per
+    // 32-column tile, the vocabulary ids n = tile + (i & 3) + 8 * (i >> 2) + 4 * h.  A wave folds its 128 columns per row,
+    // the two wave columns meet in LDS, the block writes ONE record per row.
+    float* const meet = reinterpret_cast<float*>(lds);   // [256 rows][kMsg]; every fragment read was waited for
+    float tm2[4], ts[4], tg[4], tbv[4];
+    int tbi[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + 128 * wm + 32 * mt + r;
+        const int tk = (wave_works && m < p.M && p.tok[m] >= p.v_offset) ? p.tok[m] - p.v_offset : -1;
+        float m2 = kSentinel, s = 0.0f, g = -INFINITY, bv = -INFINITY;
+        int bi = kNoIndex;
+        if (wave_works) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n_first = n0 + 128 * wn + 32 * nt + 4 * h;
+                if (p.need_argmax) fold_tile16<true>(acc[mt][nt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
+                else fold_tile16<false>(acc[mt][nt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
+            }
+        }
+        const float m2o = __shfl_xor(m2, 32, 64);
+        const float so = __shfl_xor(s, 32, 64);
+        const float go = __shfl_xor(g, 32, 64);
+        const float bvo = __shfl_xor(bv, 32, 64);
+        const int bio = __shfl_xor(bi, 32, 64);
+        ms_merge(m2, s, m2o, so);
+        g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));   // a NaN logit must not be dropped by max
+        if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+        tm2[mt] = m2; ts[mt] = s; tg[mt] = g; tbv[mt] = bv; tbi[mt] = bi;
+        if (wn == 1 && h == 0) {
+            float* q = meet + (128 * wm + 32 * mt + r) * kMsg;
+            q[0] = m2; q[1] = s; q[2] = g; q[3] = bv; q[4] = __int_as_float(bi);
+        }
+    }
+    __syncthreads();
+    if (wn != 0 || h != 0) return;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + 128 * wm + 32 * mt + r;
+        if (m >= p.M) continue;
+        const float* q = meet + (128 * wm + 32 * mt + r) * kMsg;
         float m2 = tm2[mt], s = ts[mt], g = tg[mt], bv = tbv[mt];
         int bi = tbi[mt];
         ms_merge(m2, s, q[0], q[1]);
@@ -541,20 +788,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) 
         float m2 = kSentinel, s = 0.0f, g = -INFINITY, bv = -INFINITY;
         int bi = kNoIndex;
         if (wave_works) {
-            float x[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = n0 + 32 * wv + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float v = n < p.V ? acc[mt][i] : -INFINITY;
-                if (n == tk) g = v;
-                if (v > bv || (v == bv && n < bi && n < p.V)) { bv = v; bi = n; }
-                x[i] = v;
-            }
-            float lo[8], hi[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { lo[i] = x[i]; hi[i] = x[8 + i]; }
-            accum8(lo, p.c2, m2, s);
-            accum8(hi, p.c2, m2, s);
+            const int n_first = n0 + 32 * wv + 4 * h;
+            if (p.need_argmax) fold_tile16<true>(acc[mt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
+            else fold_tile16<false>(acc[mt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
         }
         const float m2o = __shfl_xor(m2, 32, 64);
         const float so = __shfl_xor(s, 32, 64);
@@ -774,6 +1010,7 @@ int lm_head_launch(const LmHeadCall& c) {
     p.m_blocks = static_cast<int>(m_blocks);
     p.packed = packed ? 1 : 0;
     p.k_slices = 1;
+    p.need_argmax = (c.argmax_out != nullptr || c.greedy) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(c.stream);
     const int hp = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
     if (M <= kSkRows) {   // the stream-shaped kernel: every 256-column block, one record per block
@@ -782,6 +1019,20 @@ int lm_head_launch(const LmHeadCall& c) {
         p.unit0 = 0;
         p.n_blocks = static_cast<int>(blocks);
         hipLaunchKernelGGL(k_lm_head_skinny, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, p);
+        hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
+                           static_cast<int>(blocks), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
+                           c.lp_target, c.accept, c.n_acc, c.accept_bits, c.argmax_out, c.emit);
+        return launch_status();
+    }
+    if (m_blocks >= 2) {   // several row blocks per weight tile: MFMA-bound, the 4-wave kernel over every 256-column block
+        const int64_t blocks = (static_cast<int64_t>(c.V) + 255) / 256;
+        // (Cutting the tiles of the last, partial round of the CUs into reduction slices -- V = 152064, M = 1024: 2376 tiles =
+        // 9.28 rounds -- was built and measured: no gain at D = 8192, +4 % at D = 3584.  The 72 tiles of that round run
+        // faster than a tile of a full round, and a second launch + the slab traffic cost what the slices save.)
+        p.col0 = 0;
+        p.unit0 = 0;
+        p.n_blocks = static_cast<int>(blocks);
+        hipLaunchKernelGGL(k_lm_head_quad, dim3(static_cast<unsigned>(blocks * m_blocks)), dim3(kQThreads), 0, st, p);
         hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
                            static_cast<int>(blocks), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
                            c.lp_target, c.accept, c.n_acc, c.accept_bits, c.argmax_out, c.emit);

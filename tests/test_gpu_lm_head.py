@@ -93,6 +93,13 @@ def check(got, ref):
     (40, 8, 128, 4000),      # m_blocks = 2 with 32 narrow column blocks: the XCD-swizzled (mb, nb) map (n_blocks >= 8)
     (40, 8, 128, 33000),     # m_blocks = 2 with 128 WIDE blocks (swizzled) + 2 narrow blocks in the plain order
     (72, 8, 64, 3000),       # m_blocks = 3 (576 rows), 23 narrow blocks: 16 swizzled + 7 in the plain order
+    # M > 256 runs the 4-wave kernel (k_lm_head_quad: 128 x 128 per wave, register-staged operands) over every 256-column block
+    (128, 8, 256, 5000),     # M = 1024: four full row blocks, 20 column blocks (16 in the XCD-swizzled order, 4 plain, the last ragged)
+    (80, 8, 192, 4037),      # M = 640: a half row block (wave row 1 of the last block is padding), three superstages, odd V
+    (40, 8, 128, 700),       # two superstages (the short pipeline), three column blocks
+    (37, 8, 64, 300),        # ONE superstage; 296 rows: 40 real rows in the second block; ragged columns in both blocks
+    (64, 8, 512, 2304),      # M = 512, nine full column blocks
+    (96, 8, 1536, 256 * 100),         # m_blocks = 3, 300 tiles: more than one round of the CUs
 ])
 def test_lm_head_verify_matches_oracle(B, K, D, V):
     case = make_case(B, K, D, V, seed=B * 1000 + K)
@@ -100,7 +107,8 @@ def test_lm_head_verify_matches_oracle(B, K, D, V):
 
 
 @pytest.mark.parametrize("B,K,D,V", [(3, 5, 64, 300), (8, 8, 256, 1000), (32, 8, 512, 4173), (40, 8, 128, 33000),
-                                     (32, 8, 128, 66000), (32, 8, 4608, 65536 + 3 * 256 - 56), (16, 8, 192, 129)])
+                                     (32, 8, 128, 66000), (32, 8, 4608, 65536 + 3 * 256 - 56), (16, 8, 192, 129),
+                                     (128, 8, 256, 5000), (37, 8, 64, 300)])
 def test_packed_weights_give_bit_identical_results(B, K, D, V):
     """asd_lm_head_pack_weights: the tile-major image (ld_w = 0) through every kernel variant -- skinny (M <= 64), wide and
     narrow blocks, two row blocks, split-K tail tiles -- returns exactly what the [V, D] matrix returns."""
