@@ -241,6 +241,23 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
+    // the same MFMAs as ONE scheduling region with the fragment reads of the next k-step issued just before them: a read
+    // goes out behind each of the first 2 + NTW MFMAs instead of all of them in front
+    auto multiply_interleaved = [&](int set) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], hf[set][mt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int i = 0; i < 2 * NTW; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 2 + NTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     // k-steps 0..2 of superstage S are multiplied; the fragments of k-step 3 are left in register set 1
     auto head = [&](int S, auto&& late_issue) {
         if (!wave_works) {
@@ -254,9 +271,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         late_issue();
         __builtin_amdgcn_sched_barrier(0);
         read_frags(S, 2, 0);
-        multiply(1);
+        multiply_interleaved(1);
         read_frags(S, 3, 1);
-        multiply(0);
+        multiply_interleaved(0);
     };
     auto tail = [&]() {
         if (wave_works) multiply(1);
