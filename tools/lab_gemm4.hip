@@ -199,6 +199,183 @@ __global__ __launch_bounds__(256, 1) void k_gemm4(const uint16_t* __restrict__ W
     sink[static_cast<int64_t>(blockIdx.x) * 256 + t] = sum;
 }
 
+// the 32x32x16 form with TWO weight stages in registers
+// grid: (N / 256) * (M / 256) workgroups, column blocks fastest; W [N][D], H [M][D] bf16 row-major; D % 64 == 0
+__global__ __launch_bounds__(256, 1) void k_gemm4_deep(const uint16_t* __restrict__ W, const uint16_t* __restrict__ H, int M, int N,
+                                                  int D, float* __restrict__ sink) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * kSlot];     // [buffer][W | H]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv & 1, wn = wv >> 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_blocks = N / kTile;
+    // the row blocks that share a weight tile get ids 8 apart: the same XCD (round-robin dispatch) and the same dispatch round,
+    // so one of them pulls the tile from HBM and the others find it in that XCD's L2 (as the shipped kernel does)
+    const int m_blocks = M / kTile;
+    int nb, mb;
+    {
+        const int id = blockIdx.x, group = 8 * m_blocks, swizzled = (n_blocks / 8) * group;
+        if (id < swizzled) {
+            const int in_group = id % group;
+            nb = (id / group) * 8 + in_group % 8;
+            mb = in_group / 8;
+        } else {
+            mb = (id - swizzled) % m_blocks;
+            nb = (n_blocks / 8) * 8 + (id - swizzled) / m_blocks;
+        }
+    }
+    const char* wbase = reinterpret_cast<const char*>(W) + static_cast<int64_t>(nb) * kTile * D * 2;
+    const char* hbase = reinterpret_cast<const char*>(H) + static_cast<int64_t>(mb) * kTile * D * 2;
+    // staging: piece id = ps * 256 + t -> row id >> 3, 16-byte segment id & 7; LDS image XOR-swizzled like the shipped kernel
+    uint32_t goff[8], loff[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int id = ps * 256 + t;
+        const int row = id >> 3, seg = id & 7;
+        goff[ps] = static_cast<uint32_t>(row) * static_cast<uint32_t>(D * 2) + seg * 16;
+        loff[ps] = row * 128 + ((seg ^ ((row >> 1) & 7)) * 16);
+    }
+    // TWO weight stages in registers (the hidden states are L2-resident: one)
+    u32x4 swa[8], swb[8], sh[8];
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    const int key = (r >> 1) & 7;
+    const int w_off = (128 * wn + r) * 128, h_off = (128 * wm + r) * 128;
+    bf16x8 wf[2][4], hf[2][4];
+    auto read_frags = [&](int buf, int ks, int set) {
+        const unsigned char* wb = lds + buf * 2 * kSlot + w_off;
+        const unsigned char* hb = lds + buf * 2 * kSlot + kSlot + h_off;
+        const int so = ((4 * h + ks) ^ key) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf[set][i] = *reinterpret_cast<const bf16x8*>(wb + i * 32 * 128 + so);
+            hf[set][i] = *reinterpret_cast<const bf16x8*>(hb + i * 32 * 128 + so);
+        }
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], hf[set][mt], acc[mt][nt], 0, 0, 0);
+    };
+    // One scheduling region per k-step: 16 MFMAs with the 8 fragment reads of the NEXT k-step, 4 staging stores and 4 staging
+    // loads dealt between them (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read), so that the
+    // wave never issues a long run of non-MFMA instructions while the matrix pipe drains.
+    auto interleave = [&](bool reads, bool stores, bool loads) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (stores) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (loads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // 16 MFMAs with 8 fragment reads, 8 staging stores and 8 staging loads
+    auto interleave2 = [&](bool stores, bool loads) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (stores) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (loads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int n_super = D / kSuper;
+    // a quarter of the staging work -- 4 of the 16 register pieces: ds_write of stage S + 1, then the load of stage S + 2 into
+    // the same registers -- behind each of the four MFMA groups of superstage S
+    // superstage S multiplies LDS buffer S & 1; `cur` holds W(S + 1) (stored to the other buffer now, then refilled with
+    // W(S + 3)), the other register set holds W(S + 2) untouched; sh holds H(S + 1), refilled with H(S + 2)
+    auto restage = [&](u32x4 (&cur)[8], int S, int part, bool store, bool loadw, bool loadh) {
+        unsigned char* wb = lds + ((S + 1) & 1) * 2 * kSlot;
+        unsigned char* hb = wb + kSlot;
+#pragma unroll
+        for (int ps = 2 * part; ps < 2 * part + 2; ++ps) {
+            if (store) {
+                *reinterpret_cast<u32x4*>(wb + loff[ps]) = cur[ps];
+                *reinterpret_cast<u32x4*>(hb + loff[ps]) = sh[ps];
+            }
+            if (loadw) cur[ps] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + static_cast<int64_t>(S + 3) * 128 + goff[ps]));
+            if (loadh) sh[ps] = *reinterpret_cast<const u32x4*>(hbase + static_cast<int64_t>(S + 2) * 128 + goff[ps]);
+        }
+    };
+    auto superstage = [&](u32x4 (&cur)[8], int S, bool first, bool store, bool loadw, bool loadh) {
+        const int buf = S & 1;
+        read_frags(buf, 0, 0);
+        if (!first) multiply(1);
+        restage(cur, S, 0, store, loadw, loadh);
+        interleave(true, store, loadw || loadh);
+        read_frags(buf, 1, 1);
+        multiply(0);
+        restage(cur, S, 1, store, loadw, loadh);
+        interleave(true, store, loadw || loadh);
+        read_frags(buf, 2, 0);
+        multiply(1);
+        restage(cur, S, 2, store, loadw, loadh);
+        interleave(true, store, loadw || loadh);
+        read_frags(buf, 3, 1);
+        multiply(0);
+        restage(cur, S, 3, store, loadw, loadh);
+        interleave(true, store, loadw || loadh);
+        __syncthreads();
+    };
+    // prologue: stage 0 through registers into buffer 0; W(1) -> swa, H(1) -> sh, W(2) -> swb   (n_super >= 6, even, below)
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        swa[ps] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + goff[ps]));
+        sh[ps] = *reinterpret_cast<const u32x4*>(hbase + goff[ps]);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        *reinterpret_cast<u32x4*>(lds + loff[ps]) = swa[ps];
+        *reinterpret_cast<u32x4*>(lds + kSlot + loff[ps]) = sh[ps];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        swa[ps] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + 128 + goff[ps]));
+        sh[ps] = *reinterpret_cast<const u32x4*>(hbase + 128 + goff[ps]);
+        swb[ps] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + 256 + goff[ps]));
+    }
+    superstage(swa, 0, true, true, true, true);
+    int S = 1;
+    for (; S + 4 < n_super; S += 2) {
+        superstage(swb, S, false, true, true, true);
+        superstage(swa, S + 1, false, true, true, true);
+    }
+    // n_super even: the loop leaves S = n_super - 3 (odd).  swb holds W(n - 2), swa W(n - 1), sh H(n - 2): no further weights.
+    superstage(swb, S, false, true, false, true);         // stores stage n - 2, loads H(n - 1)
+    superstage(swa, S + 1, false, true, false, false);    // stores stage n - 1
+    superstage(swb, S + 2, false, false, false, false);
+    multiply(1);
+    float sum = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += acc[a][b][i];
+    sink[static_cast<int64_t>(blockIdx.x) * 256 + t] = sum;
+}
+
 // the same with v_mfma_f32_16x16x32_bf16
 // grid: (N / 256) * (M / 256) workgroups, column blocks fastest; W [N][D], H [M][D] bf16 row-major; D % 64 == 0
 __global__ __launch_bounds__(256, 1) void k_gemm4_16(const uint16_t* __restrict__ W, const uint16_t* __restrict__ H, int M, int N,
@@ -451,6 +628,7 @@ int main() {
         CHECK(hipMemcpy(dH, hH.data(), hH.size() * 2, hipMemcpyHostToDevice));
         if (run_variant(k_gemm4, false, "4 waves, mfma 32x32x16", dW, dH, sink, M, N, D)) return 1;
         if (run_variant(k_gemm4_16, true, "4 waves, mfma 16x16x32", dW, dH, sink, M, N, D)) return 1;
+        if (run_variant(k_gemm4_deep, false, "4 waves, 2 W stages in regs", dW, dH, sink, M, N, D)) return 1;
         CHECK(hipFree(dW));
         CHECK(hipFree(dH));
         CHECK(hipFree(sink));
