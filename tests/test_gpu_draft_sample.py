@@ -120,6 +120,44 @@ def test_draft_sample_reproduces_the_hf_warpers_nucleus(K_, golden):
     assert n == 54
 
 
+def test_draft_and_residual_samplers_in_a_hipgraph(K_):
+    """One launch, no workspace initialisation, nothing a capture forbids: the proposal and the commit draw replay from a
+    hipGraph with new uniforms in the same buffers."""
+    import torch
+    B, K, V = 16, 4, 32000
+    store, r = _rows(B, V, O.DT_BF16, seed=91)
+    lg = to_device_logits(store, O.DT_BF16).view(B, V)
+    rd = torch.from_numpy(r).cuda()
+    inv_t = float(np.float32(1.0 / 0.7))
+    samp = K_.DraftSampler(B, V, lg.dtype)
+    d = samp(lg, rd, inv_t, 0.9)                        # eager warm-up
+    rng = np.random.default_rng(5)
+    xt = (rng.standard_normal((B * K, V)) * 3).astype(np.float32)
+    xd = (xt + rng.standard_normal((B * K, V))).astype(np.float32)
+    st, sd = encode_logits(xt, O.DT_BF16), encode_logits(xd, O.DT_BF16)
+    t, dd = to_device_logits(st, O.DT_BF16).view(B, K, V), to_device_logits(sd, O.DT_BF16).view(B, K, V)
+    n_acc = torch.from_numpy(rng.integers(0, K, B).astype(np.int32)).cuda()
+    rs = K_.ResidualSampler(B, V, t.dtype)
+    tok_res = rs(t, dd, n_acc, rd, None, 1.0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        samp(lg, rd, inv_t, 0.9, d)
+        tok_res2 = rs(t, dd, n_acc, rd, None, 1.0)
+    for it in range(3):
+        r2 = np.random.default_rng(100 + it).uniform(0, 1, B).astype(np.float32)
+        rd.copy_(torch.from_numpy(r2))
+        g.replay()
+        torch.cuda.synchronize()
+        ref = O.draft_sample(store, O.DT_BF16, r2, B, V, inv_t, 0.9)
+        ok = (ref["margin_p"] > 1e-5) & (ref["margin_r"] > 1e-5)
+        assert ok.sum() >= B // 2
+        assert np.array_equal(d.tok.cpu().numpy()[ok], ref["tok"][ok])
+        want, margin = O.residual_sample(st, sd, O.DT_BF16, n_acc.cpu().numpy(), r2, B, K, V)
+        okr = margin > 1e-5
+        assert np.array_equal(tok_res2.cpu().numpy()[okr], want[okr])
+
+
 def test_draft_sample_strided_rows_ties_and_masked_logits(K_):
     import torch
     B, V = 6, 4096
