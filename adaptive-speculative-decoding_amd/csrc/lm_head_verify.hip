@@ -462,26 +462,22 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
 // read-ahead, 1.00 with it, 1.09 with the interleave, 1.25 with the XCD-aware block order -- the library GEMM's rate).
 constexpr int kQThreads = 256;
 
-__global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
-    constexpr int kSlot = kBM * 128;          // one operand, one superstage: 256 rows x 128 bytes
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * kSlot];     // [buffer][weights | hidden]
+constexpr int kQSlot = kBM * 128;             // one operand, one superstage: 256 rows x 128 bytes
+
+// The body of one 256-column tile.  WM x WN waves, MT x NT accumulator tiles of 32 x 32 per wave:
+//   2 x 2 waves, 4 x 4 tiles   a full row block (256 rows)
+//   1 x 4 waves, 4 x 2 tiles   the last row block when it holds <= 128 rows  (half the MFMAs)
+//   1 x 4 waves, 2 x 2 tiles   ...                       <= 64 rows           (a quarter)
+// The partial forms live in the SAME launch as the full ones: the row blocks of a weight tile run side by side on one XCD
+// and share the tile through its L2 -- a separate launch for the last row block would stream the weights from HBM again.
+template <int WM, int MT, int NT>
+__device__ __forceinline__ void quad_tile(const LmHeadParams& p, int mb, int nb, unsigned char* lds) {
+    constexpr int kSlot = kQSlot;
+    constexpr int WN = 4 / WM;
+    static_assert(WM * MT * 32 <= kBM && WN * NT * 32 == 256, "tile shape");
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int wm = wv & 1, wn = wv >> 1;
+    const int wm = wv % WM, wn = wv / WM;
     const int r = lane & 31, h = lane >> 5;
-    int mb, nb;
-    {   // the row blocks that share a weight tile get ids 8 apart: one XCD, one dispatch round (see k_lm_head_tile)
-        const int id = static_cast<int>(blockIdx.x);
-        const int group = 8 * p.m_blocks;
-        const int swizzled = (p.n_blocks / 8) * group;
-        if (id < swizzled) {
-            const int in_group = id % group;
-            nb = (id / group) * 8 + in_group % 8;
-            mb = in_group / 8;
-        } else {
-            mb = (id - swizzled) % p.m_blocks;
-            nb = (p.n_blocks / 8) * 8 + (id - swizzled) / p.m_blocks;
-        }
-    }
     const int n0 = p.col0 + nb * 256, m0 = mb * kBM;
     const int rows_w = min(256, p.V - n0), rows_h = min(kBM, p.M - m0);
     const int64_t w_stage_stride = p.packed ? 256 * 128 : kSuper * 2;
@@ -513,51 +509,44 @@ __global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
         *reinterpret_cast<u32x4v*>(wb + loff[ps]) = sw[ps];
         *reinterpret_cast<u32x4v*>(wb + kSlot + loff[ps]) = sh[ps];
     };
-    f32x16 acc[4][4];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
     // wave-uniform (made scalar: a uniform jump, not an exec mask around the k-steps): a wave of padding only stages
-    const bool wave_works = __builtin_amdgcn_readfirstlane((128 * wm < rows_h && 128 * wn < rows_w) ? 1 : 0) != 0;
+    const bool wave_works = __builtin_amdgcn_readfirstlane((32 * MT * wm < rows_h && 32 * NT * wn < rows_w) ? 1 : 0) != 0;
     const int key = (r >> 1) & 7;
-    const int w_off = (128 * wn + r) * 128, h_off = (128 * wm + r) * 128;
-    bf16x8 wf[2][4], hf[2][4];
+    const int w_off = (32 * NT * wn + r) * 128, h_off = (32 * MT * wm + r) * 128;
+    bf16x8 wf[2][NT], hf[2][MT];
     auto read_frags = [&](int buf, int ks, int set) {
         const unsigned char* wb = lds + buf * 2 * kSlot + w_off;
         const unsigned char* hb = lds + buf * 2 * kSlot + kSlot + h_off;
         const int so = ((4 * h + ks) ^ key) * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wf[set][i] = *reinterpret_cast<const bf16x8*>(wb + i * 32 * 128 + so);
-            hf[set][i] = *reinterpret_cast<const bf16x8*>(hb + i * 32 * 128 + so);
-        }
+        for (int i = 0; i < NT; ++i) wf[set][i] = *reinterpret_cast<const bf16x8*>(wb + i * 32 * 128 + so);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) hf[set][i] = *reinterpret_cast<const bf16x8*>(hb + i * 32 * 128 + so);
     };
     auto multiply = [&](int set) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], hf[set][mt], acc[mt][nt], 0, 0, 0);
     };
-    // one scheduling region: 16 MFMAs, 8 DS reads, 4 DS writes, 4 VMEM reads (masks 0x008 / 0x100 / 0x200 / 0x020)
+    // one scheduling region: MT * NT MFMAs, MT + NT DS reads, 4 DS writes, 4 VMEM reads (masks 0x008 / 0x100 / 0x200 / 0x020),
+    // dealt one non-MFMA instruction behind each MFMA while they last (reads first: the next k-step needs them soonest)
     auto interleave = [&](bool stores, bool loads) {
+        constexpr int kMfma = MT * NT, kReads = MT + NT;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kMfma; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (stores) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (loads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (i < kReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (i < kReads + 4) { if (stores) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+            else if (i < kReads + 8) { if (loads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -623,19 +612,20 @@ __global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
     // ---- epilogue (as k_lm_head_tile): D[vocab row][m column]; lane (r, h) holds row m of four 32-row tiles and, per
     // 32-column tile, the vocabulary ids n = tile + (i & 3) + 8 * (i >> 2) + 4 * h.  A wave folds its 128 columns per row,
     // the two wave columns meet in LDS, the block writes ONE record per row.
-    float* const meet = reinterpret_cast<float*>(lds);   // [256 rows][kMsg]; every fragment read was waited for
-    float tm2[4], ts[4], tg[4], tbv[4];
-    int tbi[4];
+    float* const meet = reinterpret_cast<float*>(lds);   // [WN - 1 wave columns][256 rows][kMsg]; every fragment read was waited for
+    float tm2[MT], ts[MT], tg[MT], tbv[MT];
+    int tbi[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + 128 * wm + 32 * mt + r;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = 32 * MT * wm + 32 * mt + r;
+        const int m = m0 + row;
         const int tk = (wave_works && m < p.M && p.tok[m] >= p.v_offset) ? p.tok[m] - p.v_offset : -1;
         float m2 = kSentinel, s = 0.0f, g = -INFINITY, bv = -INFINITY;
         int bi = kNoIndex;
         if (wave_works) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n_first = n0 + 128 * wn + 32 * nt + 4 * h;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n_first = n0 + 32 * NT * wn + 32 * nt + 4 * h;
                 if (p.need_argmax) fold_tile16<true>(acc[mt][nt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
                 else fold_tile16<false>(acc[mt][nt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
             }
@@ -649,26 +639,30 @@ __global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
         g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));   // a NaN logit must not be dropped by max
         if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
         tm2[mt] = m2; ts[mt] = s; tg[mt] = g; tbv[mt] = bv; tbi[mt] = bi;
-        if (wn == 1 && h == 0) {
-            float* q = meet + (128 * wm + 32 * mt + r) * kMsg;
+        if (wn != 0 && h == 0) {
+            float* q = meet + ((wn - 1) * kBM + row) * kMsg;
             q[0] = m2; q[1] = s; q[2] = g; q[3] = bv; q[4] = __int_as_float(bi);
         }
     }
     __syncthreads();
     if (wn != 0 || h != 0) return;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + 128 * wm + 32 * mt + r;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = 32 * MT * wm + 32 * mt + r;
+        const int m = m0 + row;
         if (m >= p.M) continue;
-        const float* q = meet + (128 * wm + 32 * mt + r) * kMsg;
         float m2 = tm2[mt], s = ts[mt], g = tg[mt], bv = tbv[mt];
         int bi = tbi[mt];
-        ms_merge(m2, s, q[0], q[1]);
-        const float go = q[2];
-        g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));
-        const float bvo = q[3];
-        const int bio = __float_as_int(q[4]);
-        if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+#pragma unroll
+        for (int w = 0; w < WN - 1; ++w) {             // the other wave columns, in a fixed order
+            const float* q = meet + (w * kBM + row) * kMsg;
+            ms_merge(m2, s, q[0], q[1]);
+            const float go = q[2];
+            g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));
+            const float bvo = q[3];
+            const int bio = __float_as_int(q[4]);
+            if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+        }
         float* out = p.msg + (static_cast<int64_t>(p.unit0 + nb) * p.M + m) * kMsg;
         out[0] = m2;
         out[1] = s;
@@ -676,6 +670,28 @@ __global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
         out[3] = bv;
         out[4] = __int_as_float(bi);
     }
+}
+
+__global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * kQSlot];    // [buffer][weights | hidden]
+    int mb, nb;
+    {   // the row blocks that share a weight tile get ids 8 apart: one XCD, one dispatch round (see k_lm_head_tile)
+        const int id = static_cast<int>(blockIdx.x);
+        const int group = 8 * p.m_blocks;
+        const int swizzled = (p.n_blocks / 8) * group;
+        if (id < swizzled) {
+            const int in_group = id % group;
+            nb = (id / group) * 8 + in_group % 8;
+            mb = in_group / 8;
+        } else {
+            mb = (id - swizzled) % p.m_blocks;
+            nb = (p.n_blocks / 8) * 8 + (id - swizzled) / p.m_blocks;
+        }
+    }
+    const int rows_h = min(kBM, p.M - mb * kBM);       // block-uniform: only the last row block can be partial
+    if (rows_h > 128) quad_tile<2, 4, 4>(p, mb, nb, lds);
+    else if (rows_h > 64) quad_tile<1, 4, 2>(p, mb, nb, lds);
+    else quad_tile<1, 2, 2>(p, mb, nb, lds);
 }
 
 // ---- M <= 64 rows (B*K <= 64: BASELINE configs[1], batch 8 x draft_len 8): the call is HBM-bound (64 flop per weight byte),
