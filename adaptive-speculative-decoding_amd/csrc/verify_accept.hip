@@ -484,12 +484,14 @@ struct Geometry {
 };
 
 // Launch geometry (numbers: profiles/r02_sweep_*.json, MI355X, 256 CUs, dynamic-tile kernel, preloaded arguments).
-//   rows >= CUs : one workgroup per row, no split: 512 lanes x 4-KiB tiles (B=32: 15.3 us = 5.08 TB/s against 15.6 us
-//                 for 1024 lanes x 2-KiB tiles; B=128: 49.2 us = 6.33 TB/s).
+//   rows >= CUs : one workgroup per row, no split: 512 lanes x 3-KiB tiles (B=32: 14.8-14.9 us = 5.24 TB/s against 15.0 for
+//                 2- and 4-KiB tiles and 15.3 for 1024 lanes x 2 KiB; B=128: 48.1 us = 6.47 TB/s).  A 304 KB row is 101.4 tiles
+//                 of 3 KiB: the eight waves of the workgroup end within one tile of each other, and a 3-KiB tile is a third
+//                 less to drain at the end than a 4-KiB one, while two tiles per wave still keep 48 KiB per CU in flight.
 //   rows <  CUs : split rows until ~one 512-lane workgroup per CU exists (B=8: S=4, 8.4 us); a slice is
 //                 never cut below one tile per wave.
 Geometry choose_geometry(int R, int K, int V, int dtype, int cus) {
-    Geometry g{1, 512, 4, 1};
+    Geometry g{1, 512, 3, 1};
     if (R >= cus) return g;
     g.threads = 512;
     g.unroll = 2;
@@ -521,6 +523,7 @@ template <int DT, int THREADS>
 int launch_unroll(const VerifyParams& p, int64_t grid, hipStream_t st, const Geometry& g) {
     switch (g.unroll) {
         case 2: launch_nt<DT, THREADS, 2>(p, grid, st, g.nt); return ASD_OK;
+        case 3: launch_nt<DT, THREADS, 3>(p, grid, st, g.nt); return ASD_OK;
         case 4: launch_nt<DT, THREADS, 4>(p, grid, st, g.nt); return ASD_OK;
         case 8: launch_nt<DT, THREADS, 8>(p, grid, st, g.nt); return ASD_OK;
         default: return ASD_ERR_UNSUPPORTED;
@@ -580,10 +583,10 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
     if (p.row_entropy) {   // the (m2, s, t) instantiation exists for one workgroup per row, 512 lanes x 4-KiB tiles
-        if (g.splits != 1 || g.threads != 512 || g.unroll != 4 || p.K > kFastMaxK || p.fused || p.mode != 0) return ASD_ERR_UNSUPPORTED;
+        if (g.splits != 1 || g.threads != 512 || g.unroll != 3 || p.K > kFastMaxK || p.fused || p.mode != 0) return ASD_ERR_UNSUPPORTED;
         const dim3 gd(static_cast<uint32_t>(grid / p.S), static_cast<uint32_t>(p.S));
 #define ASD_LAUNCH_STATS(DT)                                                                                      \
-    hipLaunchKernelGGL((k_verify<DT, 512, 4, true, false, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row, p.V, \
+    hipLaunchKernelGGL((k_verify<DT, 512, 3, true, false, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row, p.V, \
                        p.K, p.S, p.scale2, own_row_of(p), p)
         switch (dtype) {
             case ASD_DTYPE_BF16: ASD_LAUNCH_STATS(ASD_DTYPE_BF16); break;
@@ -596,12 +599,12 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     if (p.fused) {   // the in-kernel epilogue is instantiated for the two geometries the heuristic uses when rows >= CUs
         const dim3 gd(static_cast<uint32_t>(grid / p.S), static_cast<uint32_t>(p.S));
         const bool big = (g.threads == 1024 && g.unroll == 2);
-        if (!big && !(g.threads == 512 && g.unroll == 4)) return ASD_ERR_UNSUPPORTED;
+        if (!big && !(g.threads == 512 && g.unroll == 3)) return ASD_ERR_UNSUPPORTED;
 #define ASD_LAUNCH_FUSED(DT)                                                                                      \
     do {                                                                                                          \
         if (big) hipLaunchKernelGGL((k_verify<DT, 1024, 2, true, true>), gd, dim3(1024), 0, st, p.logits, p.tok, p.ld_row, \
                                     p.V, p.K, p.S, p.scale2, own_row_of(p), p);                                   \
-        else hipLaunchKernelGGL((k_verify<DT, 512, 4, true, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row,  \
+        else hipLaunchKernelGGL((k_verify<DT, 512, 3, true, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row,  \
                                 p.V, p.K, p.S, p.scale2, own_row_of(p), p);                                       \
     } while (0)
         switch (dtype) {
@@ -690,7 +693,7 @@ ASD_EXPORT int asd_verify_accept_stats(const void* logits, int dtype, int64_t ld
     Geometry g;
     const int rc = unpack_options(&opt, p.scale2, g);
     if (rc != ASD_OK) return rc;
-    if (row_entropy) g = Geometry{1, 512, 4, 1};   // one workgroup per row whatever the batch: the entropy's third sum is not handed across slices
+    if (row_entropy) g = Geometry{1, 512, 3, 1};   // one workgroup per row whatever the batch: the entropy's third sum is not handed across slices
     p.logits = logits; p.ld_row = ld_row; p.tok = tok; p.lp_d = lp_draft; p.u = u;
     p.B = B; p.K = K; p.V = V; p.v_offset = 0;
     p.lp_t = lp_target; p.accept = accept; p.n_acc = n_acc; p.bits = accept_bits;

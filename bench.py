@@ -869,9 +869,10 @@ def main():
     per_buf = [int(b["out"].n_acc.sum().item()) + B for b in bufs]
     tokens = sum(per_buf[(args.warmup + (i % G)) % nbuf] for i in range(args.steps))
     # kernel-only duration: back-to-back verify launches bracketed by two events, best-of-3 + mean
-    reps = max(args.steps, 100)
+    reps = max(args.steps, 200)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for i in range(1000):                     # settle: the first ~1000 launches after an idle gap run 5-15 % slower
+    for i in range(4000):                     # settle (~60 ms): the first launches after an idle gap run 5-15 % slower, and a
+                                              # short job (--steps 20) has not run long enough to reach the steady state
         verify(bufs[i % nbuf])                # (clock / memory power state ramp; measured: 18.4 -> 16.0 us over 5 runs of 400)
     torch.cuda.synchronize()
     runs = []

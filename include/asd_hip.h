@@ -97,7 +97,7 @@ typedef struct asd_verify_options {
                               at temperature 0.7 (generate_training_data.py:110-119, pipeline.py:94). */
     int splits;            /* launch geometry for tuning sweeps: workgroups per row in [1,ASD_MAX_SPLITS]; 0 = heuristic */
     int threads;           /* 256 | 512 | 1024 lanes per workgroup; 0 = heuristic */
-    int unroll;            /* tile size in KiB a wave claims at a time: 2 | 4 | 8; 0 = heuristic */
+    int unroll;            /* tile size in KiB a wave claims at a time: 2 | 3 | 4 | 8; 0 = heuristic */
     int nontemporal;       /* 0 | 1; -1 = heuristic */
 } asd_verify_options;
 
