@@ -582,7 +582,7 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     if (grid > INT32_MAX || static_cast<int64_t>(p.V) * g.splits > INT32_MAX) return ASD_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
-    if (p.row_entropy) {   // the (m2, s, t) instantiation exists for one workgroup per row, 512 lanes x 4-KiB tiles
+    if (p.row_entropy) {   // the (m2, s, t) instantiation exists for one workgroup per row, 512 lanes x 3-KiB tiles
         if (g.splits != 1 || g.threads != 512 || g.unroll != 3 || p.K > kFastMaxK || p.fused || p.mode != 0) return ASD_ERR_UNSUPPORTED;
         const dim3 gd(static_cast<uint32_t>(grid / p.S), static_cast<uint32_t>(p.S));
 #define ASD_LAUNCH_STATS(DT)                                                                                      \

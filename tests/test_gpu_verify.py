@@ -514,7 +514,7 @@ def test_verify_stats_emit_max_logprob_and_entropy(K_, dtype, B, K, V, ld):
     lg3 = lg.as_strided((B, K, V), (K * case["ld"], case["ld"], 1))
     ws = K_.VerifyWorkspace(B, K, V, lg.dtype)
     tok, lp_d, u = (torch.from_numpy(case[k]).cuda() for k in ("tok", "lp_d", "u"))
-    # the entropy form runs one 512-lane workgroup per row with 4-KiB tiles: bit-identical to the plain kernel AT THAT geometry
+    # the entropy form runs one 512-lane workgroup per row with 3-KiB tiles: bit-identical to the plain kernel AT THAT geometry
     plain = K_.verify_accept(lg3, tok, lp_d, u, ws, inv_temperature=inv_t, splits=1, threads=512, unroll=3, nontemporal=1)
     res, max_lp, ent = K_.verify_accept_stats(lg3, tok, lp_d, u, ws, inv_temperature=inv_t)
     only_max = K_.verify_accept_stats(lg3, tok, lp_d, u, ws, inv_temperature=inv_t, want_entropy=False)
