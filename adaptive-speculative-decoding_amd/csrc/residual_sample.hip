@@ -211,22 +211,23 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_mass(const RsParams p) {
     }
 }
 
-// ---- pass 3: inverse CDF --------------------------------------------------------------------
+// ---- pass 3: inverse CDF (one wave) --------------------------------------------------------------
+// tl: the row's per-tile masses (Z, P) -- in the workspace (k_rs_pick) or in LDS (k_residual_row); Lt / Ld: the rows' normalisers
+struct RsPickScratch {
+    double chunk[64];
+    double lane_mass[64];
+    int sel_tile;
+    double sel_rest;
+};
 template <int DT>
-__global__ __launch_bounds__(64) void k_rs_pick(const RsParams p) {
+__device__ __forceinline__ void rs_pick_wave(const RsParams& p, int b, int lane, const Rows<DT>& rows, const float2* tl, float Lt,
+                                             float Ld, RsPickScratch& sc) {
     using E = Elem<DT>;
     constexpr int N = E::kPerVec;
-    __shared__ double chunk[64];
-    __shared__ double lane_mass[64];
-    __shared__ int sel_tile;
-    __shared__ double sel_rest;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const Rows<DT> rows = select_rows<DT>(p, b);
-    if (!rows.xt) {
-        if (lane == 0) p.token[b] = -1;
-        return;
-    }
-    const float2* tl = p.tiles + static_cast<int64_t>(b) * p.n_tiles;
+    double (&chunk)[64] = sc.chunk;
+    double (&lane_mass)[64] = sc.lane_mass;
+    int& sel_tile = sc.sel_tile;
+    double& sel_rest = sc.sel_rest;
     // lane l owns tiles [l*per, (l+1)*per): chunk sums of Z and of P
     const int per = (p.n_tiles + 63) / 64;
     const int c0 = lane * per, c1 = min(c0 + per, p.n_tiles);
@@ -283,8 +284,6 @@ __global__ __launch_bounds__(64) void k_rs_pick(const RsParams p) {
     const double rest = sel_rest;
 
     // the chosen tile: the same float weights as pass 2, prefix over lanes then inside the lane
-    float Lt, Ld;
-    row_norms(p, b, Lt, Ld);
     const u32x4* vt = reinterpret_cast<const u32x4*>(rows.xt);
     const u32x4* vd = reinterpret_cast<const u32x4*>(rows.xd);
     const int v = tile * 64 + lane;
@@ -329,6 +328,20 @@ __global__ __launch_bounds__(64) void k_rs_pick(const RsParams p) {
         if (pick < 0) pick = last_pos;
         p.token[b] = v * N + pick;
     }
+}
+
+template <int DT>
+__global__ __launch_bounds__(64) void k_rs_pick(const RsParams p) {
+    __shared__ RsPickScratch sc;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const Rows<DT> rows = select_rows<DT>(p, b);
+    if (!rows.xt) {
+        if (lane == 0) p.token[b] = -1;
+        return;
+    }
+    float Lt, Ld;
+    row_norms(p, b, Lt, Ld);
+    rs_pick_wave<DT>(p, b, lane, rows, p.tiles + static_cast<int64_t>(b) * p.n_tiles, Lt, Ld, sc);
 }
 
 // ---- asd_draft_sample: ONE launch, one 1024-lane workgroup per row ---------------------------------------------
@@ -795,6 +808,80 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_row(const DrParams p) {
     if (lane == 0) ASD_DR_STAMP(11);
 }
 
+// ---- asd_residual_sample, many sequences: ONE launch, one 1024-lane workgroup per sequence ------------------------
+// The three-launch form above cuts every row over S workgroups: right while B x S about fills the chip (B <= 32: 21-23 us),
+// but S falls to 2 at B = 128 and the three launches take 64 us.  From B = 96 on a sequence's two rows stay in ONE
+// workgroup (the structure of k_draft_row): sweep 1 = (m2, s) of the target and of the (nucleus-masked) draft row, sweep 2
+// (L2 hits) = per-tile residual / target masses into LDS, then the inverse CDF by wave 0 -- the same rs_pick_wave.
+template <int DT>
+__global__ __launch_bounds__(kDrThreads) void k_residual_row(const RsParams p) {
+    using E = Elem<DT>;
+    constexpr int N = E::kPerVec;
+    __shared__ float2 tiles[kDrMaxTiles];
+    __shared__ float red[kDrWaves][4];
+    __shared__ RsPickScratch sc;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const Rows<DT> rows = select_rows<DT>(p, b);        // block-uniform
+    if (!rows.xt) {
+        if (t == 0) p.token[b] = -1;
+        return;
+    }
+    const u32x4* vt = reinterpret_cast<const u32x4*>(rows.xt);
+    const u32x4* vd = reinterpret_cast<const u32x4*>(rows.xd);
+    // thread t's j-th vector is v = t + 1024 j = 64 (wave + 16 j) + lane: a wave step is one 64-vector tile.  Two steps' loads
+    // are issued before the first is consumed; the trip count is wave-uniform (a ragged last tile is padded with -inf).
+    auto for_each = [&](auto&& fn) {
+        constexpr int kAhead = 2;
+        const u32x4 neg = {E::kNegInfWord, E::kNegInfWord, E::kNegInfWord, E::kNegInfWord};
+        for (int v0 = t - lane; v0 < p.nvec; v0 += kAhead * kDrThreads) {
+            u32x4 qt[kAhead], qd[kAhead];
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                const int v = v0 + j * kDrThreads + lane;
+                qt[j] = v < p.nvec ? vt[v] : neg;
+                qd[j] = (vd && v < p.nvec) ? vd[v] : neg;
+            }
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j)
+                if (v0 + j * kDrThreads < p.nvec) fn(v0 + j * kDrThreads + lane, qt[j], qd[j]);
+        }
+    };
+    float mt = kSentinel, st = 0.0f, md = kSentinel, sd = 0.0f;
+    for_each([&](int, const u32x4& a, const u32x4& d) {
+        accum_nucleus<DT>(a, rows.tthr, p.c2, mt, st);
+        if (vd) accum_nucleus<DT>(d, rows.dthr, p.c2, md, sd);
+    });
+    wave_merge(mt, st);
+    wave_merge(md, sd);
+    if (lane == 0) { red[wave][0] = mt; red[wave][1] = st; red[wave][2] = md; red[wave][3] = sd; }
+    __syncthreads();
+    mt = red[0][0]; st = red[0][1]; md = red[0][2]; sd = red[0][3];
+#pragma unroll
+    for (int w = 1; w < kDrWaves; ++w) {
+        ms_merge(mt, st, red[w][0], red[w][1]);
+        ms_merge(md, sd, red[w][2], red[w][3]);
+    }
+    const float Lt = static_cast<float>(static_cast<double>(mt) + log2_split(st));
+    const float Ld = static_cast<float>(static_cast<double>(md) + log2_split(sd));
+    for_each([&](int v, const u32x4& a, const u32x4& d) {
+        float w[N], pt[N];
+        vector_weights<DT>(a, d, vd != nullptr, p.c2, Lt, Ld, rows.tthr, rows.dthr, w, pt);
+        float z = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { z += w[i]; q += pt[i]; }
+        z = wave_sum(z);
+        q = wave_sum(q);
+        if (lane == 0) tiles[v >> 6] = make_float2(z, q);
+    });
+    __syncthreads();
+    if (wave != 0) return;
+    rs_pick_wave<DT>(p, b, lane, rows, tiles, Lt, Ld, sc);
+}
+
+// sequences from which the one-workgroup-per-sequence form is used (tools/rs_threshold_ab.sh, V = 152064 bf16: three launches
+// 31.6 / 37.8 / 50.1 / 63.9 / 116.4 us at B = 48 / 64 / 96 / 128 / 256, this form 49-55 us at every B)
+constexpr int kRsRowMinBatch = 96;
+
 template <int DT>
 int launch_rs(const RsParams& p, hipStream_t st) {
     hipLaunchKernelGGL(k_rs_lse<DT>, dim3(p.S, p.B), dim3(kRsThreads), 0, st, p);
@@ -854,6 +941,15 @@ int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, in
     p.token = token;
     p.d_thr = d_threshold;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B >= kRsRowMinBatch && p.n_tiles <= kDrMaxTiles) {
+        const dim3 grid(static_cast<unsigned>(B)), block(kDrThreads);
+        switch (dtype) {
+            case ASD_DTYPE_BF16: hipLaunchKernelGGL(k_residual_row<ASD_DTYPE_BF16>, grid, block, 0, st, p); break;
+            case ASD_DTYPE_F16: hipLaunchKernelGGL(k_residual_row<ASD_DTYPE_F16>, grid, block, 0, st, p); break;
+            default: hipLaunchKernelGGL(k_residual_row<ASD_DTYPE_F32>, grid, block, 0, st, p); break;
+        }
+        return launch_status();
+    }
     switch (dtype) {
         case ASD_DTYPE_BF16: return launch_rs<ASD_DTYPE_BF16>(p, st);
         case ASD_DTYPE_F16: return launch_rs<ASD_DTYPE_F16>(p, st);

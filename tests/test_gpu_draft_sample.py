@@ -208,11 +208,12 @@ def test_draft_lp_feeds_the_verify_step_consistently(K_):
 
 
 @pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32])
-def test_residual_sample_against_a_nucleus_truncated_draft(K_, dtype):
+@pytest.mark.parametrize("B", [16, 112])     # 112: the one-workgroup-per-sequence form of the residual draw (B >= 96)
+def test_residual_sample_against_a_nucleus_truncated_draft(K_, dtype, B):
     """asd_residual_sample_ex: p_d is the top-p truncated, renormalised draft distribution (what the drafted token
     was actually drawn from); thresholds come from asd_draft_sample on the same rows."""
     import torch
-    B, K, V = 16, 4, 32000
+    K, V = 4, 32000 if B == 16 else 8000
     rng = np.random.default_rng(5)
     xt = (rng.standard_normal((B * K, V)) * 3).astype(np.float32)
     xd = (xt + rng.standard_normal((B * K, V))).astype(np.float32)

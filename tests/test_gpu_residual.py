@@ -39,7 +39,8 @@ def _gpu(K_, st, sd, sb, n_acc, r, B, K, V, dtype, inv_t=1.0, with_bonus=True):
 
 
 @pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32, O.DT_F16])
-@pytest.mark.parametrize("B,K,V", [(32, 8, 152064), (5, 4, 1000), (3, 2, 8), (64, 8, 32000), (300, 3, 4096)])
+@pytest.mark.parametrize("B,K,V", [(32, 8, 152064), (5, 4, 1000), (3, 2, 8), (64, 8, 32000), (300, 3, 4096),
+                                   (128, 2, 152064)])     # B >= 96: one 1024-lane workgroup per sequence (k_residual_row)
 def test_residual_sample_matches_oracle(K_, dtype, B, K, V):
     st, sd, sb, n_acc, r = _case(B, K, V, dtype, seed=B + V)
     want, margin = O.residual_sample(st, sd, dtype, n_acc, r, B, K, V, bonus=sb)

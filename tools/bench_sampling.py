@@ -34,11 +34,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sampling.json"))
     ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--batches", default="8,32,128")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     V = 152064
     res = {}
-    for B in (8, 32, 128):
+    for B in [int(x) for x in a.batches.split(",")]:
         g = torch.Generator(device=dev).manual_seed(B)
         nb = 8
         rows = [(torch.randn((B, V), generator=g, device=dev) * 3).to(torch.bfloat16) for _ in range(nb)]
