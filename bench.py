@@ -919,13 +919,14 @@ def main():
                                              o.accept_bits.data_ptr(), ows.buf.data_ptr(), ows.bytes,
                                              torch.cuda.current_stream().cuda_stream)
             ob = algorithmic_bytes(oB, oK, oV)
-            # settle for ~25 ms of launches (clock / memory power state ramp after the allocation gap: a short kernel
+            # settle for ~60 ms of launches (clock / memory power state ramp after the allocation gap: a short kernel
             # needs thousands of launches for that, 300 left the B=8 figure 30 % above its steady state)
-            for i in range(max(400, int(25e-3 / (ob / 4.0e12)))):
+            for i in range(max(400, int(60e-3 / (ob / 4.0e12)))):
                 overify(obufs[i % onb])
             # a B=8 launch (8 us) is shorter than a Python ctypes call: time replays of a hipGraph of the launches
             # (same kernels, same rotating buffers), eager only if capture is refused (e.g. under a profiler)
-            og, per = None, min(onb, 24)
+            og, per = None, 24      # 24 launches per graph whatever the buffer count: a replay boundary costs ~10 us,
+                                    # 6 % of a graph of three B=128 launches
             try:
                 torch.cuda.synchronize()
                 og = torch.cuda.CUDAGraph()
