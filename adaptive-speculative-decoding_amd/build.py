@@ -31,7 +31,7 @@ SOURCES = {
     "commit.hip": [],
     "lm_head_verify.hip": ["-ffp-contract=off"],  # ends in the same finish_row arithmetic as verify_accept.hip
     "decision.hip": ["-ffp-contract=off"],
-    "predictor.hip": ["-ffp-contract=off"],
+    "predictor.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=11"],   # k_predictor_stop_w64x32's leading arguments
 }
 
 

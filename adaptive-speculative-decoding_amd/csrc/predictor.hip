@@ -185,9 +185,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_predictor_stop(const Fu
 // every global load issued up front (predictor_device.hpp: epi_prefetch / epi_finish).  This is
 // what a decode step calls (B = tens of sequences): the work is a few thousand flops, so the only
 // thing that matters is the length of the dependency chain.
-__global__ __launch_bounds__(64) void k_predictor_stop_w64x32(const FusedParams p) {
+// The first six arguments repeat the FusedParams fields the prefetch needs first (log-probs, features, packed weights): this
+// file is compiled with -amdgpu-kernarg-preload-count, so they reach every wave in SGPRs at wave start and the 40-odd loads of
+// the kernel are issued without waiting for an s_load of the kernarg segment (the struct is fetched meanwhile) -- the same
+// device as k_verify's prologue.
+__global__ __launch_bounds__(64) void k_predictor_stop_w64x32(const float* a_lp, int64_t a_ld_lp, const float* a_feat, int64_t a_ldf,
+                                                              const float* a_packed, int a_K, const FusedParams p_in) {
     __shared__ double dvals[3 * 64];
     __shared__ __attribute__((aligned(16))) float xs[64];
+    FusedParams p = p_in;
+    p.lp = a_lp; p.ld_lp = a_ld_lp; p.feat = a_feat; p.ldf = a_ldf; p.packed = a_packed; p.K = a_K;
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const bool want_stats = p.lp && (p.stats_col >= 0 || p.stats);
@@ -300,7 +307,8 @@ ASD_EXPORT int asd_predictor_stop(const float* lp, int64_t ld_lp, const int32_t*
     const int cap = current_device_cus() * 8;
     if (blocks > cap) blocks = cap;
     if (in_dim == 64 && hidden == 32 && K <= 64 && B <= 8192) {
-        hipLaunchKernelGGL(k_predictor_stop_w64x32, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), p);
+        hipLaunchKernelGGL(k_predictor_stop_w64x32, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), p.lp, p.ld_lp, p.feat,
+                           p.ldf, p.packed, p.K, p);
         return launch_status();
     }
     hipLaunchKernelGGL(k_predictor_stop, dim3(blocks), dim3(64 * kWavesPerBlock), lds, static_cast<hipStream_t>(stream), p);
