@@ -826,8 +826,8 @@ def main():
 
     # The driver runs short jobs (--steps 20 --warmup 5: a 0.4 ms timed region) on a fresh box: W steps do not bring the GPU
     # out of its idle clock / memory power state (the first ~1000 launches after an idle gap run 5-15 % slower), so the same
-    # step is launched untimed for ~20 ms first.  The W warm-up steps and the K timed steps follow unchanged.
-    SETTLE_STEPS = 1000
+    # step is launched untimed for ~120 ms first (20 ms left a fresh box 2 % short of its steady state).  The W warm-up steps and the K timed steps follow unchanged.
+    SETTLE_STEPS = 6000
     for i in range(SETTLE_STEPS):
         step(i)
     torch.cuda.synchronize()
@@ -871,7 +871,7 @@ def main():
     # kernel-only duration: back-to-back verify launches bracketed by two events, best-of-3 + mean
     reps = max(args.steps, 200)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for i in range(4000):                     # settle (~60 ms): the first launches after an idle gap run 5-15 % slower, and a
+    for i in range(8000):                     # settle (~120 ms): the first launches after an idle gap run 5-15 % slower, and a
                                               # short job (--steps 20) has not run long enough to reach the steady state
         verify(bufs[i % nbuf])                # (clock / memory power state ramp; measured: 18.4 -> 16.0 us over 5 runs of 400)
     torch.cuda.synchronize()
