@@ -40,6 +40,17 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// one 32 x 32 x 16 MFMA on fragments held as raw 16-byte vectors: bf16 or f16 operands (same lane maps, same LDS images --
+// only this instruction differs between the two element types of the call)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -110,7 +121,7 @@ __device__ __forceinline__ void fold_tile16(const f32x16& a, int n_first, int tk
 // NTW: 32-column accumulator tiles per wave: 4 (256-column block) or 2 (128-column block).
 // HPASSES: 64-row DMA passes over the hidden rows, ceil(rows / 64) for a call with M <= 256 rows (1, 2 or 4):
 // at M = 64 three quarters of the hidden-state traffic into LDS would be padding.
-template <int NTW, int HPASSES>
+template <int NTW, int HPASSES, bool F16>
 __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     constexpr int BN = 64 * NTW;             // 2 wave columns
     constexpr int kWSlot = BN * 128;         // one weight superstage
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], hf[set][mt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = mfma32<F16>(wf[set][nt], hf[set][mt], acc[mt][nt]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], hf[set][mt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = mfma32<F16>(wf[set][nt], hf[set][mt], acc[mt][nt]);
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int i = 0; i < 2 * NTW; ++i) {
@@ -470,7 +481,7 @@ constexpr int kQSlot = kBM * 128;             // one operand, one superstage: 25
 //   1 x 4 waves, 2 x 2 tiles   ...                       <= 64 rows           (a quarter)
 // The partial forms live in the SAME launch as the full ones: the row blocks of a weight tile run side by side on one XCD
 // and share the tile through its L2 -- a separate launch for the last row block would stream the weights from HBM again.
-template <int WM, int MT, int NT>
+template <int WM, int MT, int NT, bool F16>
 __device__ __forceinline__ void quad_tile(const LmHeadParams& p, int mb, int nb, unsigned char* lds) {
     constexpr int kSlot = kQSlot;
     constexpr int WN = 4 / WM;
@@ -535,7 +546,7 @@ __device__ __forceinline__ void quad_tile(const LmHeadParams& p, int mb, int nb,
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], hf[set][mt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = mfma32<F16>(wf[set][nt], hf[set][mt], acc[mt][nt]);
     };
     // one scheduling region: MT * NT MFMAs, MT + NT DS reads, 4 DS writes, 4 VMEM reads (masks 0x008 / 0x100 / 0x200 / 0x020),
     // dealt one non-MFMA instruction behind each MFMA while they last (reads first: the next k-step needs them soonest)
@@ -672,6 +683,7 @@ __device__ __forceinline__ void quad_tile(const LmHeadParams& p, int mb, int nb,
     }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * kQSlot];    // [buffer][weights | hidden]
     int mb, nb;
@@ -689,9 +701,9 @@ __global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
         }
     }
     const int rows_h = min(kBM, p.M - mb * kBM);       // block-uniform: only the last row block can be partial
-    if (rows_h > 128) quad_tile<2, 4, 4>(p, mb, nb, lds);
-    else if (rows_h > 64) quad_tile<1, 4, 2>(p, mb, nb, lds);
-    else quad_tile<1, 2, 2>(p, mb, nb, lds);
+    if (rows_h > 128) quad_tile<2, 4, 4, F16>(p, mb, nb, lds);
+    else if (rows_h > 64) quad_tile<1, 4, 2, F16>(p, mb, nb, lds);
+    else quad_tile<1, 2, 2, F16>(p, mb, nb, lds);
 }
 
 // ---- M <= 64 rows (B*K <= 64: BASELINE configs[1], batch 8 x draft_len 8): the call is HBM-bound (64 flop per weight byte),
@@ -704,6 +716,7 @@ constexpr int kSkWRing = 4;
 constexpr int kSkHRing = 3;
 constexpr int kSkRows = 64;
 
+template <bool F16>
 __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) {
     constexpr int BN = 256;
     constexpr int kWSlot = BN * 128;
@@ -777,7 +790,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) 
     auto multiply = [&](int set) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set], hf[set][mt], acc[mt], 0, 0, 0);
+            acc[mt] = mfma32<F16>(wf[set], hf[set][mt], acc[mt]);
     };
     auto compute = [&](int S) {
         if (!wave_works) return;
@@ -982,11 +995,16 @@ ASD_EXPORT size_t asd_lm_head_verify_workspace_bytes(int B, int K, int V) {
 }
 
 namespace {
+template <int NTW, bool F16>
+void launch_tile_t(int h_passes, dim3 grid, hipStream_t st, const LmHeadParams& p) {
+    if (h_passes == 1) hipLaunchKernelGGL((k_lm_head_tile<NTW, 1, F16>), grid, dim3(kThreads), 0, st, p);
+    else if (h_passes == 2) hipLaunchKernelGGL((k_lm_head_tile<NTW, 2, F16>), grid, dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_lm_head_tile<NTW, 4, F16>), grid, dim3(kThreads), 0, st, p);
+}
 template <int NTW>
-void launch_tile(int h_passes, dim3 grid, hipStream_t st, const LmHeadParams& p) {
-    if (h_passes == 1) hipLaunchKernelGGL((k_lm_head_tile<NTW, 1>), grid, dim3(kThreads), 0, st, p);
-    else if (h_passes == 2) hipLaunchKernelGGL((k_lm_head_tile<NTW, 2>), grid, dim3(kThreads), 0, st, p);
-    else hipLaunchKernelGGL((k_lm_head_tile<NTW, 4>), grid, dim3(kThreads), 0, st, p);
+void launch_tile(bool f16, int h_passes, dim3 grid, hipStream_t st, const LmHeadParams& p) {
+    if (f16) launch_tile_t<NTW, true>(h_passes, grid, st, p);
+    else launch_tile_t<NTW, false>(h_passes, grid, st, p);
 }
 
 struct LmHeadCall {
@@ -1001,7 +1019,9 @@ int lm_head_launch(const LmHeadCall& c) {
     if (!(c.inv_temperature > 0.0f) || !(c.inv_temperature < 3.0e38f)) return ASD_ERR_INVALID_ARG;
     if (c.B == 0 || c.K == 0) return ASD_OK;
     if (c.K > ASD_MAX_DRAFT_LEN) return ASD_ERR_UNSUPPORTED;
-    if (c.dtype != ASD_DTYPE_BF16 || c.D % kSuper != 0 || c.v_offset + c.V >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
+    if ((c.dtype != ASD_DTYPE_BF16 && c.dtype != ASD_DTYPE_F16) || c.D % kSuper != 0 || c.v_offset + c.V >= (1ll << 31))
+        return ASD_ERR_UNSUPPORTED;
+    const bool f16 = c.dtype == ASD_DTYPE_F16;     // hidden states and weights share the element type
     if (!c.hidden || !c.weight || !c.tok) return ASD_ERR_INVALID_ARG;
     if (c.emit == nullptr) {
         if (!c.lp_target || !c.accept || !c.n_acc) return ASD_ERR_INVALID_ARG;
@@ -1051,7 +1071,8 @@ int lm_head_launch(const LmHeadCall& c) {
         p.col0 = 0;
         p.unit0 = 0;
         p.n_blocks = static_cast<int>(blocks);
-        hipLaunchKernelGGL(k_lm_head_skinny, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, p);
+        if (f16) hipLaunchKernelGGL(k_lm_head_skinny<true>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, p);
+        else hipLaunchKernelGGL(k_lm_head_skinny<false>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, p);
         hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
                            static_cast<int>(blocks), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
                            c.lp_target, c.accept, c.n_acc, c.accept_bits, c.argmax_out, c.emit);
@@ -1065,7 +1086,8 @@ int lm_head_launch(const LmHeadCall& c) {
         p.col0 = 0;
         p.unit0 = 0;
         p.n_blocks = static_cast<int>(blocks);
-        hipLaunchKernelGGL(k_lm_head_quad, dim3(static_cast<unsigned>(blocks * m_blocks)), dim3(kQThreads), 0, st, p);
+        if (f16) hipLaunchKernelGGL(k_lm_head_quad<true>, dim3(static_cast<unsigned>(blocks * m_blocks)), dim3(kQThreads), 0, st, p);
+        else hipLaunchKernelGGL(k_lm_head_quad<false>, dim3(static_cast<unsigned>(blocks * m_blocks)), dim3(kQThreads), 0, st, p);
         hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
                            static_cast<int>(blocks), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
                            c.lp_target, c.accept, c.n_acc, c.accept_bits, c.argmax_out, c.emit);
@@ -1075,7 +1097,7 @@ int lm_head_launch(const LmHeadCall& c) {
         p.col0 = 0;
         p.unit0 = 0;
         p.n_blocks = static_cast<int>(wide);
-        launch_tile<4>(hp, dim3(static_cast<unsigned>(wide * m_blocks)), st, p);
+        launch_tile<4>(f16, hp, dim3(static_cast<unsigned>(wide * m_blocks)), st, p);
     }
     if (split_k) {
         char* const base = static_cast<char*>(c.workspace) + records_bytes(c.B, c.K, c.V);
@@ -1086,13 +1108,13 @@ int lm_head_launch(const LmHeadCall& c) {
         p.unit0 = static_cast<int>(wide);
         p.n_blocks = static_cast<int>(tail_tiles);
         p.k_slices = static_cast<int>(slices);
-        launch_tile<4>(hp, dim3(static_cast<unsigned>(tail_tiles * slices)), st, p);
+        launch_tile<4>(f16, hp, dim3(static_cast<unsigned>(tail_tiles * slices)), st, p);
         narrow = tail_tiles;          // blocks that wrote a record
     } else if (narrow > 0) {
         p.col0 = tail_col;
         p.unit0 = static_cast<int>(wide);
         p.n_blocks = static_cast<int>(narrow);
-        launch_tile<2>(hp, dim3(static_cast<unsigned>(narrow * m_blocks)), st, p);
+        launch_tile<2>(f16, hp, dim3(static_cast<unsigned>(narrow * m_blocks)), st, p);
     }
     hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
                        static_cast<int>(wide + narrow), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
@@ -1137,7 +1159,7 @@ ASD_EXPORT size_t asd_lm_head_packed_bytes(int V, int D) {
 ASD_EXPORT int asd_lm_head_pack_weights(const void* weight, int64_t ld_w, int dtype, int V, int D, void* packed,
                                         size_t packed_bytes, void* stream) {
     if (V < 1 || D < 1 || !weight || !packed || ld_w < D) return ASD_ERR_INVALID_ARG;
-    if (dtype != ASD_DTYPE_BF16 || D % kSuper != 0) return ASD_ERR_UNSUPPORTED;
+    if ((dtype != ASD_DTYPE_BF16 && dtype != ASD_DTYPE_F16) || D % kSuper != 0) return ASD_ERR_UNSUPPORTED;   // 2-byte elements: the re-layout moves bytes
     if (!aligned_to(weight, 16) || !aligned_to(packed, 16) || ld_w % 8 != 0) return ASD_ERR_ALIGNMENT;
     const size_t need = asd_lm_head_packed_bytes(V, D);
     if (packed_bytes < need) return ASD_ERR_WORKSPACE;

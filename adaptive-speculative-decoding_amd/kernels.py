@@ -182,13 +182,15 @@ def accept_from_partials(msg_all: torch.Tensor, lp_draft: torch.Tensor, u: torch
 
 class LmHeadVerifier:
     """N2: lm_head projection fused with the verify pass (asd_lm_head_verify).  Holds the partials
-    workspace for one (B, K, V); `weight` is the [V, D] bf16 lm_head matrix (nn.Linear layout)."""
+    workspace for one (B, K, V); `weight` is the [V, D] bf16 or f16 lm_head matrix (nn.Linear layout); the hidden
+    states must have the same element type."""
 
     def __init__(self, weight: torch.Tensor, B_: int, K: int, packed: bool = False):
         """packed=True: keep a tile-major copy of the matrix (asd_lm_head_pack_weights; +V*D*2 bytes) and stream that:
         every 64-deep reduction step of a column block is one contiguous 32 KiB run.  Results are bit-identical."""
-        if weight.dim() != 2 or weight.dtype != torch.bfloat16 or not weight.is_cuda:
-            raise ValueError("weight must be a [V, D] bf16 CUDA tensor")
+        if weight.dim() != 2 or weight.dtype not in (torch.bfloat16, torch.float16) or not weight.is_cuda:
+            raise ValueError("weight must be a [V, D] bf16 or f16 CUDA tensor")
+        self._dt = _DTYPE_CODE[weight.dtype]
         if weight.stride(1) != 1:
             raise ValueError("weight rows must be contiguous")
         self.weight = weight
@@ -202,7 +204,7 @@ class LmHeadVerifier:
                 raise ValueError("D must be a multiple of 64 to pack the lm_head")
             self.packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
             B.check("asd_lm_head_pack_weights", _lib().asd_lm_head_pack_weights(
-                weight.data_ptr(), weight.stride(0), B.DTYPE_BF16, self.V, self.D, self.packed.data_ptr(), nbytes, _stream()))
+                weight.data_ptr(), weight.stride(0), self._dt, self.V, self.D, self.packed.data_ptr(), nbytes, _stream()))
             self._w_ptr, self._ld_w = self.packed.data_ptr(), 0
         n = int(_lib().asd_lm_head_verify_workspace_bytes(self.B, self.K, self.V))
         self.workspace = torch.empty(max(n, 256), dtype=torch.uint8, device=weight.device)
@@ -219,8 +221,8 @@ class LmHeadVerifier:
         if not greedy and (lp_draft is None or u is None):
             raise ValueError("lp_draft and u are required unless greedy=True")
         h2 = hidden.reshape(Bv * K, hidden.shape[-1]) if hidden.dim() == 3 else hidden
-        if h2.dtype != torch.bfloat16 or h2.shape != (Bv * K, self.D) or h2.stride(1) != 1:
-            raise ValueError("hidden must be [B*K, D] bf16 with contiguous rows")
+        if h2.dtype != self.weight.dtype or h2.shape != (Bv * K, self.D) or h2.stride(1) != 1:
+            raise ValueError("hidden must be [B*K, D] of the weight's element type with contiguous rows")
         dev = h2.device
         if out is None:
             out = VerifyResult(torch.empty((Bv, K), dtype=torch.float32, device=dev),
@@ -228,7 +230,7 @@ class LmHeadVerifier:
                                torch.empty((Bv,), dtype=torch.int32, device=dev),
                                torch.empty((Bv,), dtype=torch.int64, device=dev))
         rc = _lib().asd_lm_head_verify_ex(h2.data_ptr(), h2.stride(0) if Bv * K > 1 else self.D, self._w_ptr,
-                                          self._ld_w, B.DTYPE_BF16, self.D, _dev(tok, "tok", torch.int32),
+                                          self._ld_w, self._dt, self.D, _dev(tok, "tok", torch.int32),
                                           _opt(lp_draft, "lp_draft", torch.float32), _opt(u, "u", torch.float32), Bv, K,
                                           self.V, float(inv_temperature), 1 if greedy else 0, out.lp_target.data_ptr(),
                                           out.accept.data_ptr(), out.n_acc.data_ptr(), out.accept_bits.data_ptr(),
@@ -246,12 +248,12 @@ class LmHeadVerifier:
         if (Bv, K) != (self.B, self.K):
             raise ValueError(f"verifier was sized for B={self.B}, K={self.K}, got {Bv}, {K}")
         h2 = hidden.reshape(Bv * K, hidden.shape[-1]) if hidden.dim() == 3 else hidden
-        if h2.dtype != torch.bfloat16 or h2.shape != (Bv * K, self.D) or h2.stride(1) != 1:
-            raise ValueError("hidden must be [B*K, D] bf16 with contiguous rows")
+        if h2.dtype != self.weight.dtype or h2.shape != (Bv * K, self.D) or h2.stride(1) != 1:
+            raise ValueError("hidden must be [B*K, D] of the weight's element type with contiguous rows")
         if msg is None:
             msg = torch.empty((Bv, K, 3), dtype=torch.float32, device=h2.device)
         rc = _lib().asd_lm_head_partial(h2.data_ptr(), h2.stride(0) if Bv * K > 1 else self.D, self._w_ptr,
-                                        self._ld_w, B.DTYPE_BF16, self.D, _dev(tok, "tok", torch.int32), Bv, K,
+                                        self._ld_w, self._dt, self.D, _dev(tok, "tok", torch.int32), Bv, K,
                                         self.V, int(v_offset), float(inv_temperature), _dev(msg, "msg", torch.float32),
                                         self.workspace.data_ptr(), self.workspace.numel(), _stream())
         B.check("asd_lm_head_partial", rc)

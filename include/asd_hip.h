@@ -146,8 +146,9 @@ int asd_accept_from_partials(const float* msg_all, int n_shards,
  * here  logits[b,k,v] = sum_d hidden[b,k,d] * weight[v,d]  live only in MFMA accumulators (f32)
  * and are reduced on chip to the same (m2, s, g) partials as asd_lse_partial, one per 128-column
  * vocabulary block, then combined and tested exactly like asd_accept_from_partials.
- * hidden [B*K][ld_h], weight [V][ld_w] (the nn.Linear / HF lm_head layout), both bf16 (dtype =
- * ASD_DTYPE_BF16; others: ASD_ERR_UNSUPPORTED), D % 64 == 0, ld % 8 == 0, 16-byte aligned bases.
+ * hidden [B*K][ld_h], weight [V][ld_w] (the nn.Linear / HF lm_head layout), both bf16 or both f16 (dtype =
+ * ASD_DTYPE_BF16 | ASD_DTYPE_F16 -- the reference loads its models in fp16, generate_training_data.py:79-85; f32:
+ * ASD_ERR_UNSUPPORTED), D % 64 == 0, ld % 8 == 0, 16-byte aligned bases.
  * The log-sum-exp is over UNROUNDED f32 logits, i.e. closer to the exact product than the
  * bf16-materialised path: results agree with asd_verify_accept on bf16(hidden @ weight.T) to the
  * bf16 rounding of the logits, not bit for bit (tests/test_gpu_lm_head.py states the tolerance).

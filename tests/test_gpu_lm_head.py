@@ -106,6 +106,57 @@ def test_lm_head_verify_matches_oracle(B, K, D, V):
     check(run_gpu(case), case["ref"])
 
 
+@pytest.mark.parametrize("B,K,D,V", [
+    (3, 5, 64, 300),          # skinny kernel (M <= 64)
+    (8, 8, 256, 1000),
+    (32, 8, 512, 4173),       # the 8-wave tile kernel, wide + narrow blocks
+    (32, 8, 4608, 65536 + 3 * 256 - 56),   # ... with reduction slices
+    (128, 8, 256, 5000),      # the 4-wave kernel (M > 256)
+    (37, 8, 64, 300),         # ... with a partial last row block
+])
+def test_lm_head_verify_f16_matches_oracle(B, K, D, V):
+    """The same call on f16 hidden states and weights (ASD_DTYPE_F16: the reference loads its models in fp16,
+    generate_training_data.py:79-85) -- v_mfma_f32_32x32x16_f16 on the same LDS images -- through every kernel variant, plain
+    and packed, against the f64 oracle on the f16 values."""
+    import torch
+
+    from asd_amd import kernels as Kn
+
+    rng = np.random.default_rng(B * 31 + V)
+    M = B * K
+    hb = rng.standard_normal((M, D), dtype=np.float32).astype(np.float16).view(np.uint16)
+    wb = (rng.standard_normal((V, D), dtype=np.float32) * np.float32(3.0 / np.sqrt(D))).astype(np.float16).view(np.uint16)
+    x = hb.view(np.float16).astype(np.float64) @ wb.view(np.float16).astype(np.float64).T
+    amax = x.argmax(axis=1)
+    tok = np.where(rng.uniform(size=M) < 0.7, amax, rng.integers(0, V, M)).astype(np.int32).reshape(B, K)
+    base = O.lm_head_verify(hb, wb, tok, np.zeros((B, K), np.float32), np.full((B, K), 0.5, np.float32), B, K, 1.0, dtype=O.DT_F16)
+    lp_t = base["lp_t64"]
+    lp_d = np.minimum(lp_t + rng.normal(0, 0.5, (B, K)), 0.0).astype(np.float32)
+    u = rng.uniform(0, 1, (B, K)).astype(np.float32)
+    for _ in range(100):
+        with np.errstate(divide="ignore"):
+            m = np.abs(np.log(u.astype(np.float64)) - (lp_t - lp_d.astype(np.float64)))
+        bad = ~(m >= LMH_MARGIN)
+        if not bad.any():
+            break
+        u[bad] = rng.uniform(0, 1, int(bad.sum())).astype(np.float32)
+    ref = O.lm_head_verify(hb, wb, tok, lp_d, u, B, K, 1.0, dtype=O.DT_F16)
+    w = torch.from_numpy(wb.view(np.int16)).cuda().view(torch.float16)
+    h = torch.from_numpy(hb.view(np.int16)).cuda().view(torch.float16)
+    args = (h, torch.from_numpy(tok).cuda(), torch.from_numpy(lp_d).cuda(), torch.from_numpy(u).cuda())
+    outs = []
+    for packed in (False, True):
+        r = Kn.LmHeadVerifier(w, B, K, packed=packed)(*args)
+        torch.cuda.synchronize()
+        got = dict(lp_t=r.lp_target.cpu().numpy(), accept=r.accept.cpu().numpy(), n_acc=r.n_acc.cpu().numpy(),
+                   bits=r.accept_bits.cpu().numpy().view(np.uint64))
+        check(got, ref)
+        outs.append(got)
+    assert np.array_equal(outs[0]["lp_t"], outs[1]["lp_t"])      # the packed image gives the same bits
+    with pytest.raises(ValueError):                              # operand types must agree
+        Kn.LmHeadVerifier(w, B, K)(h.to(torch.bfloat16), *args[1:])
+
+
 @pytest.mark.parametrize("B,K,D,V", [(3, 5, 64, 300), (8, 8, 256, 1000), (32, 8, 512, 4173), (40, 8, 128, 33000),
                                      (32, 8, 128, 66000), (32, 8, 4608, 65536 + 3 * 256 - 56), (16, 8, 192, 129),
                                      (128, 8, 256, 5000), (37, 8, 64, 300)])
@@ -281,7 +332,8 @@ def test_lm_head_verify_status_codes():
 
     assert call() == 0
     assert call(B=0) == 0
-    assert call(dtype=Bd.DTYPE_F16) == -2
+    assert call(dtype=Bd.DTYPE_F16) == 0           # f16 operands are served (the same bytes read as f16)
+    assert call(dtype=Bd.DTYPE_F32) == -2
     assert call(D=48, ld_h=48, ld_w=48) == -2
     assert call(D=96, ld_h=96, ld_w=96) == -2      # whole 64-column superstages only
     assert call(K=65) == -2
