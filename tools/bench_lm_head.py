@@ -45,15 +45,17 @@ def main():
     ap.add_argument("--draft-len", type=int, default=8)
     ap.add_argument("--vocab", type=int, default=152064)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16")
     a = ap.parse_args()
     B, Kk, V = a.batch, a.draft_len, a.vocab
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     M = B * Kk
     rows = []
     for name in a.shapes.split(","):
         D = SHAPES[name]
         g = torch.Generator(device="cuda").manual_seed(1)
-        h = torch.randn((M, D), device="cuda", generator=g).to(torch.bfloat16)
-        w = (torch.randn((V, D), device="cuda", generator=g) * (3.0 / D ** 0.5)).to(torch.bfloat16)
+        h = torch.randn((M, D), device="cuda", generator=g).to(dt)
+        w = (torch.randn((V, D), device="cuda", generator=g) * (3.0 / D ** 0.5)).to(dt)
         tok = torch.randint(0, V, (B, Kk), device="cuda", dtype=torch.int32)
         lp_d = -torch.rand((B, Kk), device="cuda")
         u = torch.rand((B, Kk), device="cuda")
@@ -61,8 +63,8 @@ def main():
         out_f = fused(h, tok, lp_d, u)
         packed = K.LmHeadVerifier(w, B, Kk, packed=True)
         out_p = packed(h, tok, lp_d, u)
-        ws = K.VerifyWorkspace(B, Kk, V, torch.bfloat16)
-        logits = torch.empty((M, V), dtype=torch.bfloat16, device="cuda")
+        ws = K.VerifyWorkspace(B, Kk, V, dt)
+        logits = torch.empty((M, V), dtype=dt, device="cuda")
         out_t = K.verify_accept(logits.view(B, Kk, V), tok, lp_d, u, ws)
 
         def two_step():
