@@ -616,13 +616,13 @@ def _emit(obj):
         os.write(_RESULT_FD, line)
 
 
-def sharded_verify_step(torch, dist, device, rank, world, B, K, V, D=8192, reps=30):
+def sharded_verify_step(torch, dist, device, rank, world, B, K, V, D=8192, reps=30, group=None):
     """The one exchange step of a vocab-sharded target over the ranks of this job (BASELINE configs[4]'s hot path
     without the models): every rank reduces its [V/N, D] slice of a 72B-shape lm_head to (m2, s, g) triples
     (asd_lm_head_partial, bf16 MFMA, no logits), ONE all-gather of [B,K,3] floats over RCCL, asd_accept_from_partials.
     Returns the per-step time (max over ranks) and the bytes a rank sends."""
     from asd_amd.distributed import VocabShardedVerifier
-    ver = VocabShardedVerifier(V)
+    ver = VocabShardedVerifier(V, group=group)     # `group`: the data-path (RCCL) group; control stays on the default group
     g = torch.Generator(device=device).manual_seed(77)
     hid = torch.randn((B, K, D), generator=g, device=device).to(torch.bfloat16)
     gw = torch.Generator(device=device).manual_seed(1000 + rank)
@@ -643,10 +643,12 @@ def sharded_verify_step(torch, dist, device, rank, world, B, K, V, D=8192, reps=
     t = torch.tensor([dt], dtype=torch.float64, device=red)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     n_acc = out[2]
+    data_backend = dist.get_backend(group) if group is not None else dist.get_backend()
     return {"what": "vocab-sharded verify step: asd_lm_head_partial on a [V/N, 8192] lm_head shard + all-gather [B,K,3] f32 "
                     "+ asd_accept_from_partials", "ranks": world, "batch": B, "draft_len": K, "vocab": V, "hidden": D,
             "us_per_step": 1e6 * float(t.item()), "bytes_sent_per_rank_per_step": B * K * 12 * (world - 1),
-            "tokens_per_step": int(n_acc.sum().item()) + B, "backend": dist.get_backend()}
+            "tokens_per_step": int(n_acc.sum().item()) + B, "backend": data_backend,
+            "control_backend": dist.get_backend()}
 
 
 def main():
@@ -716,13 +718,19 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1
-    red_dev = device if args.dist_backend == "nccl" else torch.device("cpu")
+    # Control (barriers, the max-over-ranks of the timings) runs over gloo on host tensors: batch-parallel replicas have NO
+    # data-path collective, so the headline must not depend on the state of RCCL / xGMI.  RCCL serves the one exchange step
+    # there is -- the all-gather of the vocab-sharded verify sub-record -- through its own group.
+    red_dev = torch.device("cpu")
+    data_group = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group("gloo")
+            try:
+                data_group = dist.new_group(backend="nccl")
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] RCCL group not created ({type(e).__name__}: {e}); sharded_verify will be skipped", file=sys.stderr)
 
     B, K, V, desc = WORKLOADS[args.workload]
     if args.scaling == "strong":
@@ -1038,7 +1046,7 @@ def main():
         try:
             bufs = cpu_buf = None
             torch.cuda.empty_cache()
-            sharded_rec = sharded_verify_step(torch, dist, device, rank, world, B, K, V)
+            sharded_rec = sharded_verify_step(torch, dist, device, rank, world, B, K, V, group=data_group)
         except Exception as e:  # noqa: BLE001
             sharded_rec = {"error": f"{type(e).__name__}: {e}"}
         pending_watchdog.cancel()
