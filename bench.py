@@ -870,8 +870,8 @@ def main():
         for i in range(args.steps):
             step(args.warmup + i)
     torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0       # this rank's K steps; the job's time is the MAX over ranks (below)
+    barrier()                                 # (the closing barrier itself -- a host round trip over gloo -- is not work)
 
     # verified tokens: outputs per buffer are deterministic, so count them after the timed region
     per_buf = [int(b["out"].n_acc.sum().item()) + B for b in bufs]
