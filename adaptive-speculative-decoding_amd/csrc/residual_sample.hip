@@ -149,21 +149,34 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_lse(const RsParams p) {
     }
 }
 
-// L = m2 + log2(s) of a whole row from its S slice partials (fixed order; every caller gets the same bits)
-__device__ __forceinline__ void row_norms(const RsParams& p, int b, float& Lt, float& Ld) {
+// A row's normaliser L = m2 + log2(s) as TWO floats (hi + lo = the f64 value to ~1e-14).  With L rounded to one float every
+// probability of the row carries the same relative error (|L| * 6e-8 * ln 2, ~4e-6 at |L| ~ 100), which is harmless for p_t or
+// p_d alone but not for their DIFFERENCE on a token that holds nearly all the mass of both rows: max(0, p_t - p_d) then has
+// that absolute error against a true value of maybe 1e-3.  The exponent is formed as fma(x, c2, -hi) - lo: the fma result is
+// exact to its own (small) magnitude, so the residual keeps ~1e-7 relative accuracy on near-deterministic rows too.
+struct Norm2 { float hi, lo; };
+__device__ __forceinline__ Norm2 norm2_of(float m2, float s) {
+    const double L = static_cast<double>(m2) + log2_split(s);
+    Norm2 n;
+    n.hi = static_cast<float>(L);
+    n.lo = static_cast<float>(L - static_cast<double>(n.hi));
+    return n;
+}
+// L of a whole row from its S slice partials (fixed order; every caller gets the same bits)
+__device__ __forceinline__ void row_norms(const RsParams& p, int b, Norm2& Lt, Norm2& Ld) {
     float mt = kSentinel, st = 0.0f, md = kSentinel, sd = 0.0f;
     for (int s = 0; s < p.S; ++s) {
         const float4 q = p.partial[static_cast<int64_t>(b) * p.S + s];
         ms_merge(mt, st, q.x, q.y);
         ms_merge(md, sd, q.z, q.w);
     }
-    Lt = static_cast<float>(static_cast<double>(mt) + log2_split(st));
-    Ld = static_cast<float>(static_cast<double>(md) + log2_split(sd));
+    Lt = norm2_of(mt, st);
+    Ld = norm2_of(md, sd);
 }
 
 // weights of one 16-byte vector: w_i = max(0, p_t - p_d), and p_t itself; returns the lane's sums
 template <int DT>
-__device__ __forceinline__ void vector_weights(const u32x4& vt, const u32x4& vd, bool has_d, float c2, float Lt, float Ld,
+__device__ __forceinline__ void vector_weights(const u32x4& vt, const u32x4& vd, bool has_d, float c2, Norm2 Lt, Norm2 Ld,
                                                float tthr, float dthr,
                                                float (&w)[Elem<DT>::kPerVec], float (&pt)[Elem<DT>::kPerVec]) {
     constexpr int N = Elem<DT>::kPerVec;
@@ -173,8 +186,8 @@ __device__ __forceinline__ void vector_weights(const u32x4& vt, const u32x4& vd,
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         // outside a row's nucleus the probability is exactly 0 (Lt / Ld are then the nucleus normalisers)
-        pt[i] = xt[i] >= tthr ? fast_exp2(fmaf(xt[i], c2, -Lt)) : 0.0f;
-        const float pd = (has_d && xd[i] >= dthr) ? fast_exp2(fmaf(xd[i], c2, -Ld)) : 0.0f;
+        pt[i] = xt[i] >= tthr ? fast_exp2(fmaf(xt[i], c2, -Lt.hi) - Lt.lo) : 0.0f;
+        const float pd = (has_d && xd[i] >= dthr) ? fast_exp2(fmaf(xd[i], c2, -Ld.hi) - Ld.lo) : 0.0f;
         w[i] = fmaxf(pt[i] - pd, 0.0f);
     }
 }
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_mass(const RsParams p) {
     const Rows<DT> rows = select_rows<DT>(p, b);
     int t0, t1;
     slice_tiles(p.n_tiles, s, p.S, t0, t1);
-    float Lt, Ld;
+    Norm2 Lt, Ld;
     row_norms(p, b, Lt, Ld);
     const u32x4* vt = reinterpret_cast<const u32x4*>(rows.xt);
     const u32x4* vd = reinterpret_cast<const u32x4*>(rows.xd);
@@ -220,8 +233,8 @@ struct RsPickScratch {
     double sel_rest;
 };
 template <int DT>
-__device__ __forceinline__ void rs_pick_wave(const RsParams& p, int b, int lane, const Rows<DT>& rows, const float2* tl, float Lt,
-                                             float Ld, RsPickScratch& sc) {
+__device__ __forceinline__ void rs_pick_wave(const RsParams& p, int b, int lane, const Rows<DT>& rows, const float2* tl, Norm2 Lt,
+                                             Norm2 Ld, RsPickScratch& sc) {
     using E = Elem<DT>;
     constexpr int N = E::kPerVec;
     double (&chunk)[64] = sc.chunk;
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(64) void k_rs_pick(const RsParams p) {
         if (lane == 0) p.token[b] = -1;
         return;
     }
-    float Lt, Ld;
+    Norm2 Lt, Ld;
     row_norms(p, b, Lt, Ld);
     rs_pick_wave<DT>(p, b, lane, rows, p.tiles + static_cast<int64_t>(b) * p.n_tiles, Lt, Ld, sc);
 }
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_row(const DrParams p) {
             unpack<DT>(vec, x);
             if (thr != -INFINITY && !any_at_least(x, thr)) return;      // a tile without a survivor keeps mass 0
             float w[N], pt[N];
-            vector_weights<DT>(vec, vec, false, p.c2, Lt, 0.0f, thr, -INFINITY, w, pt);
+            vector_weights<DT>(vec, vec, false, p.c2, Norm2{Lt, 0.0f}, Norm2{0.0f, 0.0f}, thr, -INFINITY, w, pt);
             float z = 0.0f;
 #pragma unroll
             for (int i = 0; i < N; ++i) z += pt[i];
@@ -765,7 +778,7 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_row(const DrParams p) {
     float w[N], pt[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { w[i] = 0.0f; pt[i] = 0.0f; }
-    if (v < p.nvec) { const u32x4 q = row[v]; vector_weights<DT>(q, q, false, p.c2, Lt, 0.0f, thr, -INFINITY, w, pt); }
+    if (v < p.nvec) { const u32x4 q = row[v]; vector_weights<DT>(q, q, false, p.c2, Norm2{Lt, 0.0f}, Norm2{0.0f, 0.0f}, thr, -INFINITY, w, pt); }
     double lm = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) lm += static_cast<double>(pt[i]);
@@ -861,8 +874,7 @@ __global__ __launch_bounds__(kDrThreads) void k_residual_row(const RsParams p) {
         ms_merge(mt, st, red[w][0], red[w][1]);
         ms_merge(md, sd, red[w][2], red[w][3]);
     }
-    const float Lt = static_cast<float>(static_cast<double>(mt) + log2_split(st));
-    const float Ld = static_cast<float>(static_cast<double>(md) + log2_split(sd));
+    const Norm2 Lt = norm2_of(mt, st), Ld = norm2_of(md, sd);
     for_each([&](int v, const u32x4& a, const u32x4& d) {
         float w[N], pt[N];
         vector_weights<DT>(a, d, vd != nullptr, p.c2, Lt, Ld, rows.tthr, rows.dthr, w, pt);

@@ -66,9 +66,10 @@ def main():
         got = K.ResidualSampler(B, V, t3.dtype)(t3, d3, torch.from_numpy(n_acc).cuda(), torch.from_numpy(r).cuda(),
                                                 to_device_logits(sb, dtype).view(B, V), inv_t)
         torch.cuda.synchronize()
-        # The residual max(0, p_t - p_d) is formed from f32 probabilities: with very peaked rows (|x| / T in the hundreds of
-        # log2 units, one token holding ~all the mass) the difference cancels and its relative accuracy is ~4e-6 / Z (Z = the
-        # residual's total mass), so such rows are only checked for membership of the support.
+        # The residual max(0, p_t - p_d) is formed from f32 probabilities: on rows where one token holds ~all the mass of both
+        # distributions the difference cancels down to the ulp of 1.0, i.e. a relative accuracy of ~1e-7 / Z (Z = the residual's
+        # total mass; the normalisers are carried as two floats, which removed a 30x larger term), so such rows are only
+        # checked for membership of the support.
         okr = margin > 1e-5
         if max(scale, 0.5) * inv_t <= 4.0:
             assert np.array_equal(got.cpu().numpy()[okr], want[okr]), (it, "residual", B, V, dtype, scale, T)
