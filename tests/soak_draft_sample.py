@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak: asd_draft_sample and asd_residual_sample on random shapes against the f64 oracle (dev tool).
 
-    python tools/fuzz_draft_sample.py [cases] [seed]
+    python tests/soak_draft_sample.py [cases] [seed]
 Checks, per case: the nucleus threshold bit for bit where top_p is >= 1e-5 of mass away from a cumulative-mass step, the
 token where additionally the draw is >= 1e-5 away from a CDF edge, log q within 2e-5, and always: the token lies inside the
 reported nucleus.  The residual draw: the token where the draw is >= 1e-5 away from a CDF edge."""
