@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Soak (run by hand on a GPU box, not collected by pytest): 24 random shapes with 257 <= M < 1100 -- the 4-wave
+k_lm_head_quad path: ragged rows / columns, 1-8 superstages, K up to 32 -- against the f64 oracle, through the helpers of
+tests/test_gpu_lm_head.py.
+
+    python tests/soak_lm_head_quad.py
+"""
 import sys, os, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import importlib.util
