@@ -14,9 +14,12 @@ A step = ONE pass of the hot path over one batch of synthetic target logits alre
 HBM:  asd_verify_accept (gather + log-sum-exp + acceptance test over [B,K,V] bf16)  followed by
 asd_predictor_stop (log-prob statistics -> 64-d features -> 64x32x1 predictor -> Bayes -> DP stop
 rule).  Logits buffers rotate through > 600 MB so the figure is HBM, not Infinity Cache.
-Prints ONE JSON line (rank 0).  `value` = verified tokens / s = sum_b (n_acc[b] + 1) per second,
-whole job.  N > 1: one process per GPU, every rank verifies its own batch of the same shape
-(batch-parallel replicas, no data-path collective; "weak" scaling).
+Prints ONE JSON line (rank 0; file descriptor 1 is pointed at stderr for everything else, RCCL's warnings included).
+`value` = verified tokens / s = sum_b (n_acc[b] + 1) per second, whole job.  N > 1: one process per GPU, every rank
+verifies its own batch of the same shape (batch-parallel replicas, no data-path collective; "weak" scaling); the barriers
+and the max-over-ranks of the times run over gloo, RCCL carries the one exchange step of the `sharded_verify` sub-record.
+Before the W warm-up steps the same step runs untimed for ~120 ms (a fresh box needs that to leave its idle clocks; the
+driver's job is 20 steps), and up to 64 steps are captured per graph (a short job is one replay).
 
 roofline: the verify kernel's ALGORITHMIC bytes (B*K*V*2 + 17*B*K + 4*B, +8*B for
 the ballot word) divided by its mean launch duration.  Duration = HIP events recorded on the launch
