@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sampling.json"))
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--batches", default="8,32,128")
+    ap.add_argument("--scale", type=float, default=3.0, help="logits = scale * N(0,1): 3 = a wide nucleus (hundreds of tokens at "
+                    "T = 0.7, top-p 0.9), 8 = a peaked row (a handful of tokens), closer to a confident LLM step")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     V = 152064
@@ -42,7 +44,7 @@ def main():
     for B in [int(x) for x in a.batches.split(",")]:
         g = torch.Generator(device=dev).manual_seed(B)
         nb = 8
-        rows = [(torch.randn((B, V), generator=g, device=dev) * 3).to(torch.bfloat16) for _ in range(nb)]
+        rows = [(torch.randn((B, V), generator=g, device=dev) * a.scale).to(torch.bfloat16) for _ in range(nb)]
         r = torch.rand((B,), generator=g, device=dev)
         ds = K.DraftSampler(B, V, torch.bfloat16, dev)
         out = None
