@@ -21,6 +21,7 @@ import torch  # noqa: E402
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     top_p = float(sys.argv[2]) if len(sys.argv) > 2 else 0.9
+    scale = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0
     V = 152064
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
@@ -31,7 +32,7 @@ def main():
     lib = C.CDLL(lib_path)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(5)
-    logits = (torch.randn((B, V), generator=g, device=dev) * 3.0).to(torch.bfloat16)
+    logits = (torch.randn((B, V), generator=g, device=dev) * scale).to(torch.bfloat16)
     r = torch.rand((B,), generator=g, device=dev)
     tok = torch.zeros((B,), dtype=torch.int32, device=dev)
     lp = torch.zeros((B,), dtype=torch.float32, device=dev)
