@@ -3,6 +3,11 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5]
 
+N > 1 runs one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks
+come from the launcher (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment); started as a plain process
+(`python bench.py --gpus N`, WORLD_SIZE unset) bench.py is its own launcher: before anything touches the GPU it starts the
+N ranks as child processes, relays rank 0's line and exits non-zero if a rank fails (_spawn_ranks).
+
 Launch modes (--mode): `graph` (default) captures runs of steps in one hipGraph on one stream;
 `eager` is plain stream-ordered launches (within 2 % of graph here: the loop is GPU-bound);
 `overlap` forks each step's epilogue to a side stream inside the graph -- measured 29 us/step vs
@@ -391,7 +396,7 @@ def main_lm_head(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if os.environ.get("ASD_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -523,7 +528,7 @@ def main_tiers(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if os.environ.get("ASD_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -654,8 +659,114 @@ def sharded_verify_step(torch, dist, device, rank, world, B, K, V, D=8192, reps=
             "control_backend": dist.get_backend()}
 
 
+def _spawn_ranks(n, argv, timeout_s):
+    """`bench.py --gpus N` started as a plain process (no torch.distributed.run, WORLD_SIZE unset): THIS process never
+    touches the GPU -- it has not imported torch -- and starts the N ranks as children (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, rendezvous on 127.0.0.1), relays rank 0's one JSON line to its own stdout and exits
+    non-zero if any rank failed.  Children are started with subprocess (fork + exec of a process that holds no GPU
+    state) and ended by their exact PIDs; the torch.distributed.run path is unchanged (WORLD_SIZE set => no spawn)."""
+    import socket
+    import subprocess
+    import threading
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs, lines = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ASD_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+
+    def pump():
+        for raw in procs[0].stdout:
+            lines.append(raw.decode(errors="replace").rstrip("\n"))
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    deadline = time.monotonic() + timeout_s
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = f"ranks still running after {timeout_s:.0f} s"
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:                       # exactly the processes started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    th.join(timeout=10)
+    result = None
+    for ln in lines:
+        try:
+            obj = json.loads(ln)
+        except ValueError:
+            print(ln, file=sys.stderr)
+            continue
+        if isinstance(obj, dict) and "metric" in obj:
+            result = ln
+        else:
+            print(ln, file=sys.stderr)
+    if failed:
+        print(f"[bench] {failed}", file=sys.stderr)
+        return 1
+    if result is None:
+        print("[bench] rank 0 printed no result line", file=sys.stderr)
+        return 1
+    sys.stdout.write(result + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def main_dry(args):
+    """`--dry-run`: the launcher, the rendezvous, the barriers and the max-over-ranks reduction of the N-rank job with NO
+    kernel and no GPU (gloo on host tensors).  The line says so (`value` null): it is a test of the plumbing that the CPU
+    suite can run (tests/test_bench_launcher.py), never a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    if args.dry_fail_rank == rank:
+        raise SystemExit(3)                   # test hook: a rank that dies must fail the whole job
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    if rank == 0:
+        B, K, V, desc = WORKLOADS[args.workload]
+        _emit({"metric": "verified_tokens_per_s", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
+               "vs_baseline": None, "dtype": "bf16", "data": "none (dry run of the launcher: no kernel ran)",
+               "dry_run": True, "config": {"workload": f"{args.workload}: {desc}", "parallelism": f"{world} rank(s), gloo, no GPU",
+                                           "spawned_by_bench": os.environ.get("ASD_BENCH_SPAWNED") == "1"}})
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
-    _quiet_rccl_banner()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -697,7 +808,18 @@ def main():
     ap.add_argument("--lam", type=float, default=None, help="lambda of the loop (default: calibrated to --stop-rate)")
     ap.add_argument("--stop-rate", type=float, default=0.66, help="target share of blocks whose tier-1 verdict is final "
                     "(the reference reports 66.2 %% of requests served by its first stage, README.md:91-94)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction plumbing only: no kernel, no GPU, `value` null (CPU test of --gpus N)")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="--gpus N started without torch.distributed.run: seconds after which the spawned ranks are ended")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher BEFORE anything initialises the GPU (torch is not imported yet)
+        sys.exit(_spawn_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
+    _quiet_rccl_banner()
+    if args.dry_run:
+        return main_dry(args)
     if args.lm_head:
         return main_lm_head(args)
     if args.placement in ("tiers", "sharded-target"):
@@ -713,7 +835,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if os.environ.get("ASD_BENCH_ONE_DEVICE") == "1":

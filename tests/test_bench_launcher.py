@@ -1,0 +1,68 @@
+"""bench.py --gpus N as its own launcher: a plain `python bench.py --gpus N` must not depend on
+torch.distributed.run.  CPU tests drive the launcher, the rendezvous and the reduction with `--dry-run` (no kernel, no
+GPU, `value` null -- plumbing only); the GPU test runs the real replica step on two ranks that share cuda:0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra)
+    return env
+
+
+def _one_line(stdout: str):
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_plain_process_spawns_its_ranks_and_prints_one_line(n):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--dry-run", "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == n and d["dry_run"] is True and d["value"] is None
+    assert d["config"]["spawned_by_bench"] is True
+
+
+def test_torchrun_path_still_works():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631", BENCH, "--gpus", "2", "--dry-run",
+                        "--steps", "5", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["spawned_by_bench"] is False
+
+
+def test_a_failing_rank_fails_the_job_without_a_line():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--dry-fail-rank", "1", "--launch-timeout", "60"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+
+
+def test_world_size_mismatch_is_an_error():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--no-loop"], capture_output=True, text=True, timeout=300,
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_replica_ranks_on_one_gpu_from_a_plain_process():
+    """The real step (asd_verify_accept_fused on resident logits) on two self-spawned ranks sharing cuda:0; control over gloo."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "20", "--warmup", "5",
+                        "--no-loop", "--no-cpu-baseline", "--no-other-workloads"], capture_output=True, text=True,
+                       timeout=600, env=_env(ASD_BENCH_ONE_DEVICE="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["frac"] < 1.0
