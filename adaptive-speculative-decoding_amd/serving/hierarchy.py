@@ -411,8 +411,12 @@ class VerifyRole:
         d_full = torch.zeros_like(t_rows)
         thr = torch.full((m,), float("-inf"), dtype=torch.float32, device=dev)
         if b_rows.numel():
+            if d_rows.dtype != t_rows.dtype:
+                # the nucleus threshold was taken on the draft row AS STORED: a cast could move tokens across it
+                raise ValueError(f"draft rows are {d_rows.dtype}, this tier's logits {t_rows.dtype}: the tiers of a hierarchy "
+                                 "must produce logits of one storage dtype")
             where = torch.searchsorted(b_sel, b_rows)       # b_sel ascending (idx and sel are)
-            d_full[where] = d_rows.to(t_rows.dtype)
+            d_full[where] = d_rows
             thr[where] = d_thr
         all_acc = (j >= K).to(torch.int32)                  # K = 1 view: 0 -> residual of the two rows, 1 -> bonus draw
         tokd = self.ops.residual_sample(t_rows[:, None, :], d_full[:, None, :], all_acc.contiguous(), self._r[b_sel].contiguous(),
@@ -557,13 +561,23 @@ class Placement:
 
 class Wire:
     """Point-to-point movement of the fixed-shape messages between roles; roles that share a rank hand the
-    tensors over directly.  Counts the bytes that really crossed a link."""
+    tensors over directly.  Counts the bytes that really crossed a link.
 
-    def __init__(self, rank: int, device, group=None):
+    loopback=True (tests, one GPU): a message between two roles of the SAME rank also goes through the backend --
+    one grouped isend + irecv of the rank to itself (ncclSend / ncclRecv inside one ncclGroup on RCCL) -- instead of the
+    direct hand-over, so that the device-tensor transport of the `nccl` backend executes on a box with a single GPU.
+    The received copy replaces the original; the committed stream must not change (tests/test_gpu_hierarchy.py)."""
+
+    def __init__(self, rank: int, device, group=None, loopback: bool = False):
         self.rank, self.device, self.group = rank, device, group
         self.staged = dist.is_initialized() and host_staged(group) and torch.device(device).type == "cuda"
+        self.loopback = bool(loopback) and dist.is_initialized()
         self.local: Dict[Tuple[str, int, int], List[torch.Tensor]] = {}
         self.bytes: Dict[str, int] = {}
+
+    def _to_wire(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        return t.cpu() if (t.is_cuda and self.staged) else t
 
     def send(self, name: str, tensors: Sequence[torch.Tensor], src: int, dsts: Sequence[int]) -> None:
         if self.rank != src:
@@ -573,14 +587,33 @@ class Wire:
                 self.local[(name, src, d)] = list(tensors)
                 continue
             for t in tensors:
-                t = t.contiguous()
+                t = self._to_wire(t)
                 if t.numel():
-                    dist.send(t.cpu() if (t.is_cuda and self.staged) else t, dst=d, group=self.group)
+                    dist.send(t, dst=d, group=self.group)
                     self.bytes[name] = self.bytes.get(name, 0) + t.numel() * t.element_size()
+
+    def _through_backend(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        if not t.numel():
+            return t
+        src = self._to_wire(t)
+        if host_staged(self.group):             # gloo has no pair of a rank with itself: the host staging alone
+            dst = src.clone()
+        else:
+            dst = torch.empty_like(src)
+            me = dist.get_rank()                # P2POp peers are global ranks
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, me, self.group),
+                                             dist.P2POp(dist.irecv, dst, me, self.group)]):
+                w.wait()
+        key = name + " (loopback)"
+        self.bytes[key] = self.bytes.get(key, 0) + src.numel() * src.element_size()
+        return dst.to(self.device)
 
     def recv(self, name: str, like: Sequence[Tuple[Tuple[int, ...], torch.dtype]], src: int) -> List[torch.Tensor]:
         if self.rank == src:
-            return self.local.pop((name, src, src))
+            got = self.local.pop((name, src, src))
+            if self.loopback:
+                got = [self._through_backend(name, t) for t in got]
+            return got
         out = []
         for shape, dtype in like:
             dev = "cpu" if self.staged else self.device
@@ -594,7 +627,8 @@ class Wire:
 @torch.no_grad()
 def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[DraftRole], tiers: Dict[int, VerifyRole],
                           B: int, K: int, L: int, V: int, logits_dtype: torch.dtype, cap: int, device,
-                          max_steps: Optional[int] = None, group=None, keep_inputs: bool = False) -> HierarchyTrace:
+                          max_steps: Optional[int] = None, group=None, keep_inputs: bool = False,
+                          loopback: bool = False) -> HierarchyTrace:
     """One rank of the multi-rank loop.  `draft` is the DraftRole if this rank hosts tier 0, `tiers` maps stage index
     -> VerifyRole for the verify tiers this rank hosts (leader or vocab shard).  Every rank executes the same step
     sequence; only the messages listed in the module docstring cross ranks.  The committed stream is identical to
@@ -604,10 +638,13 @@ def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[Draft
     leader(s) -> D: verdict;  D -> ranks(s): draft rows of the stop-with-rejection sequences;  leader(s) -> D: drawn.
     D learns whether tier s+1 runs from tier s's verdict (active and not stopped), tier s+1 from the escalate
     message; both are the same data, so every rank takes the same branch."""
-    wire = Wire(rank, device, group)
+    wire = Wire(rank, device, group, loopback=loopback)
     D = placement.draft
     verify_ranks = sorted({r for t in placement.tiers for r in t})
     everyone = sorted({D} | set(verify_ranks))
+    if rank not in everyone:                  # a rank the placement gives no role (world > 6): nothing to run, nothing to wait for
+        empty = torch.zeros((0,), dtype=torch.int32, device=device)
+        return HierarchyTrace(empty, empty, tier_counts=[0] * L, tier_calls=[0] * L)
     state = draft.st if draft is not None else next(iter(tiers.values())).st
     tr = HierarchyTrace(state.tokens, state.seq_len, tier_counts=[0] * L, tier_calls=[0] * L)
     limit = max_steps if max_steps is not None else cap + 4

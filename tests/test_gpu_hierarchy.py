@@ -262,6 +262,47 @@ def test_multi_rank_drivers_with_hip_kernels_on_one_gpu(world, mode):
         assert dict(ret) == {r: "ok" for r in range(world)}
 
 
+def test_rank_driver_over_a_one_rank_rccl_group_with_loopback():
+    """run_hierarchical_rank + Wire on the `nccl` backend (RCCL) with DEVICE tensors: a 1-rank group and
+    Wire(loopback=True), so every message between the roles of the rank is one grouped ncclSend + ncclRecv of the rank to
+    itself instead of the direct hand-over.  (Two ranks need two GPUs: RCCL refuses two ranks on one device.)  The
+    committed stream must equal generate_hierarchical's."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from asd_amd.distributed import HipOps
+    from asd_amd.serving import hierarchy as H
+    from tests.test_hierarchy import _model, _predictor, _prompt
+    dt, dev = torch.bfloat16, torch.device("cuda", 0)
+    cfg = H.HierarchyConfig(draft_len=K, temperature=0.7, top_p=0.9, lambda_value=25.0, seed=3)
+
+    def build():
+        ops, pred, prompt = HipOps(), _predictor(), _prompt().cuda()
+        d = H.DraftRole(_model(0, 0, dt, dev), cfg, ops, prompt, NEW, pred)
+        tiers = {}
+        for s, (noise, seed) in enumerate(zip((0.02, 0.04), (5, 6)), start=1):
+            m = _model(noise, seed, dt, dev)
+            tiers[s] = H.VerifyRole(m, s, cfg, ops, prompt, NEW, pred, head=H.LogitsHead(m, ops))
+        return d, tiers
+    d1, t1 = build()
+    want = H.generate_hierarchical(d1, [t1[1], t1[2]])
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        assert not H.host_staged(None)
+        d, t = build()
+        got = H.run_hierarchical_rank(0, H.Placement.for_world(1), d, t, B, K, 3, V, dt, P + NEW, dev, loopback=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got.tokens, want.tokens) and got.tier_counts == want.tier_counts
+        looped = {k: v for k, v in got.bytes_sent.items() if k.endswith("(loopback)")}
+        assert set(looped) >= {"draft (loopback)", "verdict (loopback)", "drawn (loopback)", "final (loopback)"}
+        assert all(v > 0 for v in looped.values())
+    finally:
+        dist.destroy_process_group()
+
+
 def test_three_tier_loop_at_the_production_vocabulary():
     """The same loop with V = 152064 (Qwen2.5) rows: every kernel of the step at the size the path runs at -- nucleus
     select over 152064 logits, verify from [n, K, 152064] bf16 logits and from hidden states, residual draws."""

@@ -280,3 +280,40 @@ def test_placements_follow_the_reference_yaml():
     assert Placement.for_world(2).tiers == [[0], [1]] and Placement.for_world(2).draft == 0
     assert Placement.for_world(4).tiers == [[1], [2, 3]]
     assert Placement.for_world(8).tiers == [[1], [2, 3, 4, 5]]      # tensor_parallel_size 4 (configs/qwen3_models.yaml:46)
+
+
+def test_rank_driver_alone_with_loopback_transport_equals_the_single_process_loop():
+    """World size 1 with Wire(loopback=True): every message between the roles of the one rank goes through the backend
+    (a grouped isend + irecv to itself) instead of the direct hand-over.  The committed stream must not change.  The GPU
+    twin of this test runs the same thing over a 1-rank RCCL group (tests/test_gpu_hierarchy.py)."""
+    from asd_amd.serving import hierarchy as H
+    from tests.oracle_backend import OracleOps
+    want, cfg, prompt = _single(keep=False)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        ops, pred = OracleOps(), _predictor()
+        pl = H.Placement.for_world(1)
+        d = H.DraftRole(_model(0, 0), cfg, ops, prompt, NEW, pred)
+        tiers = {}
+        for s_, (noise, seed) in enumerate(zip((0.02, 0.04), (5, 6)), start=1):
+            m = _model(noise, seed)
+            tiers[s_] = H.VerifyRole(m, s_, cfg, ops, prompt, NEW, pred, head=H.LogitsHead(m, ops))
+        got = H.run_hierarchical_rank(0, pl, d, tiers, B, K, 3, V, torch.float32, P + NEW, torch.device("cpu"), loopback=True)
+        assert torch.equal(got.tokens, want.tokens) and got.tier_counts == want.tier_counts
+        looped = {k: v for k, v in got.bytes_sent.items() if k.endswith("(loopback)")}
+        assert set(looped) >= {"draft (loopback)", "verdict (loopback)", "drawn (loopback)", "final (loopback)"} and all(v > 0 for v in looped.values())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_without_a_role_returns_at_once():
+    """Placement.for_world(8) uses ranks 0..5 (7B | 32B | 72B over four ranks): ranks 6 and 7 have no role and must
+    neither raise nor wait for a message."""
+    from asd_amd.serving import hierarchy as H
+    pl = H.Placement.for_world(8)
+    assert sorted({pl.draft} | {r for t in pl.tiers for r in t}) == [0, 1, 2, 3, 4, 5]
+    tr = H.run_hierarchical_rank(7, pl, None, {}, B, K, 3, V, torch.float32, P + NEW, torch.device("cpu"), max_steps=2)
+    assert tr.steps == 0 and tr.verified_tokens == 0
