@@ -37,10 +37,15 @@ SIGNATURES = {
     "asd_verify_accept_fused": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                      _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d, _i, _i, _i, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp]),
+    "asd_verify_accept_fused_ex": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
+                                        _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d, _i, _i, _i, _vp,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "asd_debug_verify_withhold": (_i, [_i]),
     "asd_residual_sample_workspace_bytes": (_sz, [_i, _i, _i]),
     "asd_residual_sample": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "asd_residual_sample_ex": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "asd_draft_sample_workspace_bytes": (_sz, [_i, _i, _i]),
+    "asd_debug_draft_groups": (_i, [_i]),
     "asd_draft_sample": (_i, [_vp, _i64, _i, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "asd_lse_partial": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
     "asd_accept_from_partials": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -28,6 +28,7 @@ SOURCES = {
     # hosts the in-kernel epilogue (predictor_device.hpp); the streaming prologue's arguments are preloaded into SGPRs
     "verify_accept.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=11"],
     "residual_sample.hip": [],
+    "draft_sample.hip": [],
     "commit.hip": [],
     "lm_head_verify.hip": ["-ffp-contract=off"],  # ends in the same finish_row arithmetic as verify_accept.hip
     "decision.hip": ["-ffp-contract=off"],
@@ -54,16 +55,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers += [os.path.join(INC, "asd_hip.h"), os.path.abspath(__file__)]
-    objs = []
+    objs, jobs = [], []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc, *COMMON, *extra, "-c", s, "-o", o]
+            jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+    if jobs:                                   # one hipcc per translation unit, side by side (each is single-threaded)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
         if verbose:

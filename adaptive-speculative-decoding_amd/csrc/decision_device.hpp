@@ -15,14 +15,16 @@ __device__ __forceinline__ double bayes_adjust1(double p_hat, double n_obs, doub
     return posterior_alpha / (posterior_alpha + posterior_beta); // :126
 }
 
-// dp_solver.py:12-71 for one request; p, C: L values; J: L+1 values out.  Returns k*.
-__device__ __forceinline__ int optimal_stopping1(const double (&p_in)[ASD_MAX_STAGES], const double (&C)[ASD_MAX_STAGES],
-                                                 double lam, int L, int risk, double alpha, double beta,
-                                                 double (&J)[ASD_MAX_STAGES + 1]) {
-    double p_bar[ASD_MAX_STAGES + 1];
+// dp_solver.py:12-71 for one request; p, C: L values; J: L+1 values out.  Returns k*.  MAXS bounds L at compile time (the
+// arrays live in registers: a kernel that only ever sees 3- or 4-tier hierarchies instantiates MAXS = 4).
+template <int MAXS>
+__device__ __forceinline__ int optimal_stopping_n(const double (&p_in)[MAXS], const double (&C)[MAXS],
+                                                  double lam, int L, int risk, double alpha, double beta,
+                                                  double (&J)[MAXS + 1]) {
+    double p_bar[MAXS + 1];
     p_bar[0] = 1.0;                                              // :42
 #pragma unroll
-    for (int i = 0; i < ASD_MAX_STAGES; ++i) {
+    for (int i = 0; i < MAXS; ++i) {
         if (i < L) {
             const double pi = risk ? bayes_adjust1(p_in[i], 100.0, alpha, beta) : p_in[i];  // :38-39
             p_bar[i + 1] = p_bar[i] * pi;                        // :44
@@ -31,10 +33,10 @@ __device__ __forceinline__ int optimal_stopping1(const double (&p_in)[ASD_MAX_ST
     int k_star = L - 1;                                          // :67 fallback
     double next = 0.0;                                           // J[L] = 0 :47
 #pragma unroll
-    for (int i = ASD_MAX_STAGES; i >= 0; --i)
+    for (int i = MAXS; i >= 0; --i)
         if (i == L) J[i] = 0.0;
 #pragma unroll
-    for (int i = ASD_MAX_STAGES - 1; i >= 0; --i) {              // :51 reversed(range(L))
+    for (int i = MAXS - 1; i >= 0; --i) {                        // :51 reversed(range(L))
         if (i < L) {
             const double cost_if_stop = C[i] + lam * (1 - p_bar[i + 1]);   // :53
             const double cost_if_continue = C[i] + next;                   // :56
@@ -45,6 +47,12 @@ __device__ __forceinline__ int optimal_stopping1(const double (&p_in)[ASD_MAX_ST
         }
     }
     return k_star;
+}
+
+__device__ __forceinline__ int optimal_stopping1(const double (&p_in)[ASD_MAX_STAGES], const double (&C)[ASD_MAX_STAGES],
+                                                 double lam, int L, int risk, double alpha, double beta,
+                                                 double (&J)[ASD_MAX_STAGES + 1]) {
+    return optimal_stopping_n<ASD_MAX_STAGES>(p_in, C, lam, L, risk, alpha, beta, J);
 }
 
 // minimal_adaptive_decoder.py:153-164

@@ -59,7 +59,8 @@ __device__ __forceinline__ double np_lerp(double a, double b, double t) {
 
 // One wave computes the five statistics of vals[0..n) (f64, in LDS); `sorted` and `sq` are LDS
 // scratch of n doubles each.  Result valid in lane 0.
-static __device__ void wave_logprob_stats(double* vals, double* sorted, double* sq, int n, int lane, double (&out)[5]) {
+template <bool SMALL>
+static __device__ void wave_logprob_stats_t(double* vals, double* sorted, double* sq, int n, int lane, double (&out)[5]) {
     if (n <= 0) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) out[i] = 0.0;             // features.extend([0.0]*5) :174-175
@@ -79,7 +80,8 @@ static __device__ void wave_logprob_stats(double* vals, double* sorted, double* 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double mean = 0.0;
-    if (lane == 0) mean = np_sum(vals, n) / static_cast<double>(n);          // np.mean :168
+    // SMALL: n <= 128 is known (the in-kernel epilogue: n = K <= 64), where numpy's pairwise sum IS its leaf routine
+    if (lane == 0) mean = (SMALL ? np_sum_leaf(vals, n) : np_sum(vals, n)) / static_cast<double>(n);          // np.mean :168
     mean = __shfl(mean, 0, 64);
     for (int i = lane; i < n; i += 64) {
         const double t = vals[i] - mean;
@@ -89,7 +91,7 @@ static __device__ void wave_logprob_stats(double* vals, double* sorted, double* 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane == 0) {
-        const double var = np_sum(sq, n) / static_cast<double>(n);            // np.std :169 (population)
+        const double var = (SMALL ? np_sum_leaf(sq, n) : np_sum(sq, n)) / static_cast<double>(n);            // np.std :169 (population)
         const double vi = static_cast<double>(n - 1) * 0.25;                  // np.percentile(.,25) :171
         const int lo = static_cast<int>(floor(vi));
         const int hi = lo + 1 < n ? lo + 1 : n - 1;
@@ -99,6 +101,10 @@ static __device__ void wave_logprob_stats(double* vals, double* sorted, double* 
         out[3] = np_lerp(sorted[lo], sorted[hi], vi - static_cast<double>(lo));
         out[4] = (n & 1) ? sorted[n / 2] : (sorted[n / 2 - 1] + sorted[n / 2]) / 2.0;  // np.median :172
     }
+}
+
+static __device__ void wave_logprob_stats(double* vals, double* sorted, double* sq, int n, int lane, double (&out)[5]) {
+    wave_logprob_stats_t<false>(vals, sorted, sq, n, lane, out);
 }
 
 // ---- fused epilogue: parameters and the lane-0 decision tail -----------------------------
@@ -171,6 +177,32 @@ __device__ __forceinline__ void decide_and_store_impl(const FusedParams& p, int 
         p.thr_stop[b] = (q >= th || p.stage_idx == p.L - 1) ? 1 : 0;
     }
 }
+// the same tail for hierarchies of at most kDecidePrefetch stages, everything from the prefetch: a fraction of the registers
+// (the general form keeps 16-stage arrays alive; k_verify<FUSED> is launched for L <= kDecidePrefetch only)
+__device__ __forceinline__ void decide_and_store_small(const FusedParams& p, int b, float sc, const DecidePrefetch& d) {
+    if (p.score) p.score[b] = sc;
+    double prob = static_cast<double>(sc);
+    if (p.risk) prob = bayes_adjust1(prob, p.n_obs, p.alpha, p.beta);
+    if (p.p_hist) {
+        p.p_hist[static_cast<int64_t>(b) * p.L + p.stage_idx] = prob;
+        if (p.k_star || p.stop) {
+            const int n_dp = p.prefix ? p.stage_idx + 1 : p.L;
+            double pp[kDecidePrefetch], cc[kDecidePrefetch], J[kDecidePrefetch + 1];
+#pragma unroll
+            for (int i = 0; i < kDecidePrefetch; ++i) {
+                pp[i] = (i == p.stage_idx) ? prob : d.ph[i];
+                cc[i] = d.cc[i];
+            }
+            const int ks = optimal_stopping_n<kDecidePrefetch>(pp, cc, p.lam, n_dp, 0, 1.0, 1.0, J);
+            if (p.k_star) p.k_star[b] = ks;
+            if (p.stop) p.stop[b] = (ks == p.stage_idx) ? 1 : 0;
+        }
+    }
+    if (p.theta && p.thr_stop) {
+        const double q = static_cast<double>(sc);
+        p.thr_stop[b] = (q >= d.theta || p.stage_idx == p.L - 1) ? 1 : 0;
+    }
+}
 __device__ __forceinline__ void decide_and_store(const FusedParams& p, int b, float sc) {
     DecidePrefetch none;
     decide_and_store_impl<false>(p, b, sc, none);
@@ -232,6 +264,58 @@ __device__ __forceinline__ void epi_finish(const FusedParams& p, int b, int lane
     for (int off = 16; off >= 1; off >>= 1) z += __shfl_xor(z, off, 64);
     const float sc = 1.0f / (1.0f + expf(-(z + e.b2)));
     if (lane == 0) decide_and_store_impl<true>(p, b, sc, e.d);
+}
+
+
+// ---- the same epilogue for a kernel that cannot afford the weights in registers while it streams (k_verify<FUSED>:
+// 55 more VGPRs took it to 135 and to ONE workgroup per CU).  The packed weights sit in LDS (put there by LDS-DMA at the
+// kernel's start: no register is held across the stream); the feature and the decision inputs are loaded LATE -- issued by
+// the finisher right before it waits for the hand-off slots, i.e. under a wait that is there anyway.  Same operations in
+// the same order as epi_finish: bit-identical scores.
+struct EpiLate {
+    float xv;
+    DecidePrefetch d;      // lane 0 only
+};
+__device__ __forceinline__ void epi_late_prefetch(const FusedParams& p, int b, int lane, EpiLate& e) {
+    e.xv = p.feat[static_cast<int64_t>(b) * p.ldf + lane];
+    if (lane == 0) decide_prefetch(p, b, e.d);
+}
+// wl: the 64 * 32 + 65 packed floats in LDS (W1^T [in][hidden], b1, W2, b2)
+__device__ __forceinline__ void epi_finish_lds(const FusedParams& p, int b, int lane, float lpv, int n, bool want_stats,
+                                               const float* wl, const EpiLate& e, double* dvals, float* xs) {
+    float xv = e.xv;
+    if (want_stats) {
+        double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (lane < n) dvals[lane] = static_cast<double>(lpv);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_logprob_stats_t<true>(dvals, dvals + 64, dvals + 128, n, lane, st);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) st[i] = __shfl(st[i], 0, 64);
+        if (p.stats && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
+        }
+        const int si = lane - p.stats_col;
+        if (p.stats_col >= 0 && si >= 0 && si < 5)
+            xv = static_cast<float>(si == 0 ? st[0] : si == 1 ? st[1] : si == 2 ? st[2] : si == 3 ? st[3] : st[4]);
+    }
+    xs[lane] = xv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int j = lane & 31, half = lane >> 5;
+    float h = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) h = fmaf(wl[(half * 32 + i) * 32 + j], xs[half * 32 + i], h);
+    h += __shfl_xor(h, 32, 64);
+    h = fmaxf(h + wl[64 * 32 + j], 0.0f);
+    float z = half == 0 ? wl[64 * 32 + 32 + j] * h : 0.0f;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) z += __shfl_xor(z, off, 64);
+    const float sc = 1.0f / (1.0f + expf(-(z + wl[64 * 32 + 64])));
+    if (lane == 0) decide_and_store_small(p, b, sc, e.d);
 }
 
 }  // namespace asd

@@ -24,20 +24,28 @@
 // payload store, no drain, no read-back on the tail.
 //
 // Split rows (S > 1; few rows, many CUs).
-// Hand-off.  The slice result is published as ONE self-tagging 8-byte granule (write-through, agent
-// scope; never all-zero, an empty slot is) and the publishing lane takes a ticket on the
-// sequence's counter without draining the store (round 2: the drain was a round trip on every tail).  The workgroup whose ticket is the last of the sequence's K*S tickets
-// stages the K*S granules of the K candidate rows in LDS, combines the S slices of every row in
-// slice order (=> bitwise deterministic, independent of arrival order), gathers the drafted
-// token's logit, runs the acceptance test, and turns the K accept flags into the sequence's
-// accept mask / accepted-prefix length with one wave ballot.  Nothing spins: there is no wait
-// anywhere in the kernel.  Granule regions are per sequence and padded to whole 256-byte blocks,
-// so every line of them has exactly one reader per launch (MI355X_MICROARCH.md, inter-workgroup
-// visibility: sc1 stores + drained ticket + sc1 loads).  Every sequence's ticket / ballot word sits in
-// its own 128-byte line: atomics on one line serialise at the memory side (measured: 32 tickets
-// packed in one line made 4096 arrivals cost 80 us).  The last arriver resets the ticket, so a
-// workspace zeroed once serves every later stream-ordered call (hipGraph-replay safe: no epoch
-// argument, no memset node).
+// Hand-off.  The slice result is published as ONE self-tagging 8-byte granule (write-through, agent scope; never
+// all-zero, an empty slot is) and the publishing lane takes a ticket on the sequence's counter WITHOUT draining the
+// store (the drain was a store-ack round trip on every slice's tail).  The workgroup whose ticket is the last of the
+// sequence's K*S tickets stages the K*S granules of the K candidate rows in LDS -- it re-reads a slot that is still
+// empty: every store it waits for was ISSUED before the ticket add that made it the finisher, so the wait is one store
+// latency; the loop is bounded (2^20 polls), and a slot that never fills POISONS its row (lp_t = NaN, rejected; the
+// in-kernel epilogue then reports score = NaN, k* = L - 1, stop = 0) instead of folding a zero -- hands every slot back
+// empty, combines the S slices of every row in slice order (=> bitwise deterministic, independent of arrival order),
+// gathers the drafted token's logit, runs the acceptance test, and turns the K accept flags into the sequence's accept
+// mask / accepted-prefix length with one wave ballot.  With the in-kernel epilogue (FUSED) the same wave, which now
+// holds all K lp_t in its lanes, runs the predictor / stop rule on the spot: no hand-off of its own.
+// Workspace invariant: ticket words, ballot words, lp slots and granule slots are ZERO between calls (asd_workspace_init
+// once; every call hands back what it used), whatever B / K / S the calls had -- so calls of different shapes may share
+// one workspace in stream order.  Granule regions are per sequence and padded to whole 256-byte blocks, so every line of
+// them has exactly one reader per launch.  Every sequence's ticket / ballot word sits in its own 128-byte line: atomics
+// on one line serialise at the memory side (measured: 32 tickets packed in one line made 4096 arrivals cost 80 us).
+// hipGraph-replay safe: no epoch argument, no memset node.
+//
+// In-kernel epilogue on the one-workgroup-per-row path: every row hands its lp_t to the sequence's finisher as a
+// self-tagging 8-byte slot (1 << 32 | bits of lp_t) in lines 1-2 of the sequence's workspace block, again without a
+// drain; the arrival that completes the ballot polls the K slots (bounded, poisoning as above), zeroes them, and its
+// whole wave runs epi_finish.
 //
 // Reference arithmetic this replaces: src/training/generate_training_data.py:128-136
 // (softmax -> index -> log -> .item(), one token per iteration).  The acceptance test has no
@@ -53,7 +61,7 @@ __device__ unsigned long long* g_asd_stamps = nullptr;
 #define ASD_STAMP_AT(slot)                                                                       \
     do {                                                                                         \
         if (threadIdx.x == 0 && g_asd_stamps)                                                    \
-            g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+            g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define ASD_STAMP_AT(slot) do { } while (0)
@@ -63,8 +71,9 @@ namespace asd {
 namespace {
 
 constexpr int kMaxStage = 1024;        // granules one finisher stages in LDS (K*S <= kMaxStage)
-constexpr int kTicketStride = 64;      // u32 units: 256 bytes per sequence = ticket/ballot line + one line of K lp_t values
-constexpr int kLpLineOffset = 32;      // u32 units: where the fused epilogue's lp_t hand-off line starts
+constexpr int kTicketStride = 128;     // u32 units: 512 bytes per sequence = ticket/ballot line + two lines of K lp_t slots (+ one spare)
+constexpr int kLpLineOffset = 32;      // u32 units: where the fused epilogue's lp_t hand-off slots start (kFastMaxK x 8 bytes)
+constexpr int kSpinLimit = 1 << 20;    // polls of a slot whose store is in flight before its row is poisoned
 constexpr int kFastMaxK = 32;          // ballot-by-atomic packs K flags + a 32-bit count in one u64
 
 struct VerifyParams {
@@ -88,8 +97,30 @@ struct VerifyParams {
     float* row_max_lp;   // [B,K] out or nullptr: max_v log softmax(x / T)[v]  (= -ln s: free in the epilogue)
     float* row_entropy;  // [B,K] out or nullptr: entropy (nats) of softmax(x / T); needs the STATS instantiation
     int fused;           // != 0: the sequence's last arriver also runs the predictor / stop epilogue (N1)
+    int withhold1;       // debug (asd_debug_verify_withhold): 1 + (row * S + split) of the workgroup that never publishes its slot; 0 = off
     FusedParams epi;     // asd_predictor_stop's parameters (lp / n_valid unused: the kernel's own lp_t, all K)
 };
+
+// bounded wait for a self-tagging slot (non-zero = published); 0 after kSpinLimit polls = lost
+__device__ __forceinline__ uint64_t poll_slot(uint64_t* slot) {
+    uint64_t v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spins = 0; v == 0ull && spins < kSpinLimit; ++spins) {   // in flight, not lost: see the publishing side
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return v;
+}
+
+// the epilogue's outputs for a sequence whose hand-off was lost: nothing downstream may read them as a verdict
+__device__ __forceinline__ void epi_poison(const FusedParams& e, int b) {
+    if (e.score) e.score[b] = NAN;
+    if (e.k_star) e.k_star[b] = e.L - 1;
+    if (e.stop) e.stop[b] = 0;
+    if (e.thr_stop) e.thr_stop[b] = 0;
+    if (e.stats) {
+        for (int i = 0; i < ASD_NUM_LP_STATS; ++i) e.stats[ASD_NUM_LP_STATS * static_cast<int64_t>(b) + i] = NAN;
+    }
+}
 
 template <int DT, int UNROLL, bool CHECK, bool STATS>
 __device__ __forceinline__ void consume(const u32x4 (&r)[UNROLL], uint32_t off, uint32_t end, float c2, float& m2, float& s,
@@ -137,11 +168,12 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     __shared__ uint32_t next_tile;
     __shared__ __attribute__((aligned(16))) uint64_t stage[kMaxStage];   // tile slots while streaming, then scratch of the finisher
     __shared__ float stage_t[STATS ? kMaxStage : 1];                      // STATS: the tiles' third value
+    __shared__ __attribute__((aligned(16))) float wlds[FUSED ? 64 * 32 + 68 : 4];   // FUSED: the predictor's packed weights (LDS-DMA)
 
     ASD_STAMP_AT(0);
 #ifdef ASD_STAMP
     if (threadIdx.x == 0 && g_asd_stamps)   // HW_REG_XCC_ID (id 20), all 32 bits
-        g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
+        g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -226,10 +258,23 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     if (do_tail) raw_tail = E::raw(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + (lane - 32));
     const int b = static_cast<int>(static_cast<uint32_t>(row) / static_cast<uint32_t>(a_K));
     const int k = row - b * a_K;
-    EpiPrefetch pre;
-    const bool fused = FUSED && own_row && p.mode == 0;
+    const bool fused = FUSED && p.mode == 0;   // one workgroup per row: the sequence's designated finisher; split rows: the last arriver
     if (FUSED) {
-        if (fused && wave == 0) epi_prefetch(p.epi, b, lane, pre);   // features + predictor weights, also under the stream
+        // The predictor's 2113 packed weights go STRAIGHT into LDS (global_load_lds: no VGPR is held across the stream; as
+        // registers they took this instantiation to 135 VGPRs = one workgroup per CU), issued under the stream by the waves
+        // that can end up running the epilogue: the designated finisher (the sequence's last row) with one workgroup per row,
+        // any slice's wave 0 with split rows.  8 x 1 KiB (W1^T), then b1 / W2 (64 floats) and b2 as dwords.
+        if (fused && wave == 0 && (!own_row || k == a_K - 1)) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            typedef const __attribute__((address_space(1))) void glb_void;
+            const char* src = reinterpret_cast<const char*>(p.epi.packed);
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps)
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + ps * 1024 + lane * 16), (lds_void*)(reinterpret_cast<char*>(wlds) + ps * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + 8192 + lane * 4), (lds_void*)(reinterpret_cast<char*>(wlds) + 8192), 4, 0, 0);
+            if (lane == 0)
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + 8192 + 256), (lds_void*)(reinterpret_cast<char*>(wlds) + 8192 + 256), 4, 0, 0);
+        }
     }
 
 #define ASD_CLAIM(dst)                                                                                   \
@@ -273,7 +318,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     ASD_STAMP_AT(2);
 #ifdef ASD_STAMP
     if (lane == 0 && g_asd_stamps)   // per-wave stream end, after the per-workgroup records
-        g_asd_stamps[static_cast<size_t>(gridDim.x * gridDim.y) * 8 + static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
+        g_asd_stamps[static_cast<size_t>(gridDim.x * gridDim.y) * 16 + static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (wave == 0) {
         // the small loads issued ahead of the loop are consumed here: head / tail elements -> slot n_tiles,
@@ -325,7 +370,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
 
     if (own_row) {
         // ---- one workgroup per row: finish the row here ---------------------------------------
-        if (!fused && lane != 0) return;
+        if (!(FUSED && fused) && lane != 0) return;
         if (p.mode == 1) {
             p.msg[3 * row + 0] = m2;
             p.msg[3 * row + 1] = s;
@@ -333,7 +378,54 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             return;
         }
         uint32_t* line = p.tickets + static_cast<int64_t>(b) * kTicketStride;
-        int last = 0;
+        if (FUSED && fused) {
+            // ---- in-kernel epilogue, one workgroup per row.  No ballot atomic at all: every row hands (lp_t, accept flag) to
+            // the sequence's DESIGNATED finisher -- the workgroup of its last row, dispatched after its siblings -- as one
+            // self-tagging 8-byte slot, write-through and not drained; the finisher polls the K - 1 slots (bounded; a lost
+            // slot poisons the epilogue), hands them back empty, forms the accept mask with a wave ballot and runs the
+            // predictor / stop rule on the spot.  (Round 2: slot store + DRAIN + returning ballot atomic + read-back by the
+            // last arriver = two more memory round trips on the tail.)
+            float lp = 0.0f;
+            bool flag = false;
+            if (lane == 0) {
+                flag = finish_row(m2, s, x_tok, c2, lpd, lu_row, lp);
+                p.lp_t[row] = lp;
+                p.accept[row] = flag ? 1 : 0;
+                if (p.row_max_lp) p.row_max_lp[row] = row_max_logprob(s);
+            }
+            uint64_t* slots = reinterpret_cast<uint64_t*>(line + kLpLineOffset);
+            const uint64_t mine = (1ull << 63) | (static_cast<uint64_t>(flag ? 1u : 0u) << 32) | __float_as_uint(lp);
+            if (k != p.K - 1) {
+                if (lane == 0 && row + 1 != p.withhold1) __hip_atomic_store(slots + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            ASD_STAMP_AT(4);
+            EpiLate late;
+            epi_late_prefetch(p.epi, b, lane, late);        // feature + decision inputs: in flight while the slots are polled
+            uint64_t sv = __shfl(mine, 0, 64);              // the finisher's own row (lane K - 1 keeps it)
+            if (lane < p.K - 1) {
+                sv = poll_slot(slots + lane);
+                __hip_atomic_store(slots + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // empty again for the next call
+            }
+            const bool lost = lane < p.K && sv == 0ull;
+            const unsigned long long bal = __ballot(lane < p.K && ((sv >> 32) & 1ull));
+            if (lane == 0) {
+                const unsigned long long inv = ~bal;
+                const int n = inv ? __builtin_ctzll(inv) : 64;
+                p.n_acc[b] = n < p.K ? n : p.K;
+                if (p.bits) p.bits[b] = bal;
+            }
+            ASD_STAMP_AT(5);
+            if (__ballot(lost) != 0ull) {
+                if (lane == 0) epi_poison(p.epi, b);
+                return;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the weights (issued at the kernel's start) has landed
+            epi_finish_lds(p.epi, b, lane, __uint_as_float(static_cast<uint32_t>(sv)), p.K, p.epi.stats_col >= 0 || p.epi.stats != nullptr,
+                           wlds, late, reinterpret_cast<double*>(stage), reinterpret_cast<float*>(stage + 192));
+            ASD_STAMP_AT(8);
+            return;
+        }
         if (lane == 0) {
             float lp;
             const bool flag = finish_row(m2, s, x_tok, c2, lpd, lu_row, lp);
@@ -343,17 +435,12 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             if (STATS) {
                 if (p.row_entropy) p.row_entropy[row] = row_entropy_nats(m2, s, tsum, c2);
             }
-            if (fused) {   // hand lp_t to whoever finishes the sequence: write-through store, drained before the ticket
-                __hip_atomic_store(line + kLpLineOffset + k, __float_as_uint(lp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
             // ballot by atomic: count in the high word, this row's flag at bit k of the low word
             uint64_t* word = reinterpret_cast<uint64_t*>(line + 2);
             const uint64_t mine = (1ull << 32) | (static_cast<uint64_t>(flag ? 1u : 0u) << k);
             ASD_STAMP_AT(4);
             const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (static_cast<uint32_t>(old >> 32) == static_cast<uint32_t>(p.K - 1)) {
-                last = 1;
                 const uint32_t mask = static_cast<uint32_t>(old | mine);
                 const uint32_t inv = ~mask;
                 const int n = inv ? __builtin_ctz(inv) : 32;
@@ -363,20 +450,8 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             }
 #ifdef ASD_STAMP
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (g_asd_stamps) g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime() + (old & 0);
+            if (g_asd_stamps) g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 5] = __builtin_amdgcn_s_memrealtime() + (old & 0);
 #endif
-        }
-        if (!fused) return;
-        if (FUSED) {
-            last = __shfl(last, 0, 64);
-            if (!last) return;
-            // ---- last arriver of the sequence, whole wave: statistics of the K log-probs -> features ->
-            // predictor -> Bayes -> DP rule (predictor_device.hpp), on the values the K rows handed over
-            float lpv = 0.0f;
-            if (lane < p.K)
-                lpv = __uint_as_float(__hip_atomic_load(line + kLpLineOffset + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            epi_finish(p.epi, b, lane, lpv, p.K, p.epi.stats_col >= 0 || p.epi.stats != nullptr, pre,
-                       reinterpret_cast<double*>(stage), reinterpret_cast<float*>(stage + 192));
         }
         return;
     }
@@ -393,7 +468,8 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         // add whose return value made it the finisher, so the wait is bounded by one store latency -- and hands the
         // slot back empty.
         const uint64_t g = (static_cast<uint64_t>(__float_as_uint(s)) << 32) | __float_as_uint(m2);
-        __hip_atomic_store(region + k * S + split, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (row * S + split + 1 != p.withhold1)
+            __hip_atomic_store(region + k * S + split, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = (old == static_cast<uint32_t>(KS - 1));
     }
@@ -401,6 +477,10 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     if (!last) return;
 
     // ---- last arriver of sequence b: finish its K rows ------------------------------------
+    EpiLate late;
+    if (FUSED) {
+        if (fused) epi_late_prefetch(p.epi, b, lane, late);   // under the token / logit gathers and the granule polls below
+    }
     const int frow = b * p.K + lane;  // lane <-> draft position
     if (lane < p.K) {
         const int64_t t = static_cast<int64_t>(p.tok[frow]) - p.v_offset;
@@ -409,12 +489,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         if (p.mode == 0) { lpd = p.lp_d[frow]; uu = p.u[frow]; }
     }
     for (int g = lane; g < KS; g += 64) {
-        uint64_t v = __hip_atomic_load(region + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int spins = 0; v == 0ull && spins < (1 << 20); ++spins) {   // in flight, not lost: see the publishing side
-            __builtin_amdgcn_s_sleep(1);
-            v = __hip_atomic_load(region + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        stage[g] = v;
+        stage[g] = poll_slot(region + g);       // 0 = lost: poisons its row below
         __hip_atomic_store(region + g, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // empty again for the next call
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -422,11 +497,14 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     float fm = kSentinel, fs = 0.0f;
+    bool lost = false;
     if (lane < p.K) {
         for (int j = 0; j < S; ++j) {
             const uint64_t g = stage[lane * S + j];
+            lost = lost || g == 0ull;
             ms_merge(fm, fs, __uint_as_float(static_cast<uint32_t>(g)), __uint_as_float(static_cast<uint32_t>(g >> 32)));
         }
+        if (lost) { fm = NAN; fs = NAN; }       // a slice never arrived: lp_t = NaN, the row is rejected
     }
     if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
@@ -439,14 +517,28 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         return;
     }
     bool flag = false;
+    float lp = 0.0f;
     if (lane < p.K) {
-        float lp;
         flag = finish_row(fm, fs, x_tok, c2, lpd, log_u(uu), lp);
         p.lp_t[frow] = lp;
         p.accept[frow] = flag ? 1 : 0;
         if (p.row_max_lp) p.row_max_lp[frow] = row_max_logprob(fs);
     }
     finish_sequence(flag, lane, p.K, b, p.n_acc, p.bits);
+    if (FUSED) {
+        if (!fused) return;
+        // the finisher's lanes hold all K lp_t: the predictor / stop epilogue runs right here (no hand-off at all)
+        if (__ballot(lost) != 0ull) {
+            if (lane == 0) epi_poison(p.epi, b);
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the staged granules are dead; `stage` is the epilogue's scratch
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the LDS-DMA of the weights has landed
+        epi_finish_lds(p.epi, b, lane, lp, p.K, p.epi.stats_col >= 0 || p.epi.stats != nullptr, wlds, late,
+                       reinterpret_cast<double*>(stage), reinterpret_cast<float*>(stage + 192));
+        ASD_STAMP_AT(8);
+    }
 }
 
 // combine all-gathered per-shard partials; one wave per sequence
@@ -540,7 +632,10 @@ int launch_threads(const VerifyParams& p, int64_t grid, hipStream_t st, const Ge
     }
 }
 
+int g_debug_withhold = -1;   // asd_debug_verify_withhold (tests only; not thread-safe by design)
+
 int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_bytes, void* stream, Geometry g) {
+    p.withhold1 = g_debug_withhold + 1;
     if (p.B < 0 || p.K < 0 || p.V < 0) return ASD_ERR_INVALID_ARG;
     if (p.B == 0 || p.K == 0) return ASD_OK;
     if (p.K > ASD_MAX_DRAFT_LEN) return ASD_ERR_UNSUPPORTED;
@@ -596,15 +691,16 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
 #undef ASD_LAUNCH_STATS
         return launch_status();
     }
-    if (p.fused) {   // the in-kernel epilogue is instantiated for the two geometries the heuristic uses when rows >= CUs
+    if (p.fused) {   // the in-kernel epilogue is instantiated for the two geometries the heuristic uses: rows >= CUs
+                     // (512 lanes x 3-KiB tiles, one workgroup per row) and rows < CUs (512 x 2 KiB, split rows)
         const dim3 gd(static_cast<uint32_t>(grid / p.S), static_cast<uint32_t>(p.S));
-        const bool big = (g.threads == 1024 && g.unroll == 2);
-        if (!big && !(g.threads == 512 && g.unroll == 3)) return ASD_ERR_UNSUPPORTED;
+        const bool wide = (g.threads == 512 && g.unroll == 3);
+        if (!wide && !(g.threads == 512 && g.unroll == 2)) return ASD_ERR_UNSUPPORTED;
 #define ASD_LAUNCH_FUSED(DT)                                                                                      \
     do {                                                                                                          \
-        if (big) hipLaunchKernelGGL((k_verify<DT, 1024, 2, true, true>), gd, dim3(1024), 0, st, p.logits, p.tok, p.ld_row, \
-                                    p.V, p.K, p.S, p.scale2, own_row_of(p), p);                                   \
-        else hipLaunchKernelGGL((k_verify<DT, 512, 3, true, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row,  \
+        if (wide) hipLaunchKernelGGL((k_verify<DT, 512, 3, true, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row, \
+                                     p.V, p.K, p.S, p.scale2, own_row_of(p), p);                                  \
+        else hipLaunchKernelGGL((k_verify<DT, 512, 2, true, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row,  \
                                 p.V, p.K, p.S, p.scale2, own_row_of(p), p);                                       \
     } while (0)
         switch (dtype) {
@@ -702,35 +798,41 @@ ASD_EXPORT int asd_verify_accept_stats(const void* logits, int dtype, int64_t ld
     return launch_verify(p, dtype, workspace, workspace_bytes, stream, g);
 }
 
-ASD_EXPORT int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,
-                                       const float* lp_draft, const float* u, int B, int K, int V, float* lp_target,
-                                       uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits, void* workspace,
-                                       size_t workspace_bytes, const float* feat, int64_t ldf, int stats_col,
-                                       const float* packed_w, int in_dim, int hidden, int risk_adjustment, int64_t n_obs,
-                                       double alpha, double beta, double* p_hist, const double* C, double lam, int L,
-                                       int stage_idx, int prefix_rule, const double* theta, float* score,
-                                       int32_t* k_star, uint8_t* stop, uint8_t* thr_stop, double* stats, void* stream) {
+ASD_EXPORT int asd_verify_accept_fused_ex(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,
+                                          const float* lp_draft, const float* u, int B, int K, int V, float* lp_target,
+                                          uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits, void* workspace,
+                                          size_t workspace_bytes, const float* feat, int64_t ldf, int stats_col,
+                                          const float* packed_w, int in_dim, int hidden, int risk_adjustment, int64_t n_obs,
+                                          double alpha, double beta, double* p_hist, const double* C, double lam, int L,
+                                          int stage_idx, int prefix_rule, const double* theta, float* score,
+                                          int32_t* k_star, uint8_t* stop, uint8_t* thr_stop, double* stats,
+                                          const asd_verify_options* opt, void* stream) {
     if (B > 0 && K > 0 && (!lp_draft || !u || !lp_target || !accept || !n_acc)) return ASD_ERR_INVALID_ARG;
     if (L < 1 || stage_idx < 0 || stage_idx >= L) return ASD_ERR_INVALID_ARG;
     if (L > ASD_MAX_STAGES) return ASD_ERR_UNSUPPORTED;
     if (B > 0 && (!feat || !packed_w || ldf < in_dim)) return ASD_ERR_INVALID_ARG;
     if (stats_col >= 0 && stats_col + ASD_NUM_LP_STATS > in_dim) return ASD_ERR_INVALID_ARG;
     if ((k_star || stop) && (!p_hist || !C)) return ASD_ERR_INVALID_ARG;
-    const int64_t R = static_cast<int64_t>(B) * K;
-    const bool in_kernel = in_dim == 64 && hidden == 32 && K <= kFastMaxK && R >= current_device_cus();
-    if (!in_kernel) {   // shapes the in-kernel epilogue does not cover: same results from two launches
-        const int rc = asd_verify_accept(logits, dtype, ld_row, tok, lp_draft, u, B, K, V, lp_target, accept, n_acc,
-                                         accept_bits, workspace, workspace_bytes, stream);
+    VerifyParams p{};
+    Geometry g;
+    const int rc0 = unpack_options(opt, p.scale2, g);
+    if (rc0 != ASD_OK) return rc0;
+    // the in-kernel epilogue is the reference's 64 -> 32 -> 1 predictor over a hierarchy of <= 4 tiers (the reference's: 3 or 4)
+    // at the heuristic's geometries; any other predictor shape, depth or forced geometry gets the same results from two launches
+    const bool geometry_ok = (g.threads == 0 || g.threads == 512) && (g.unroll == 0 || g.unroll == 2 || g.unroll == 3);
+    const bool in_kernel = in_dim == 64 && hidden == 32 && geometry_ok && L <= kDecidePrefetch;
+    if (!in_kernel) {
+        const int rc = asd_verify_accept_ex(logits, dtype, ld_row, tok, lp_draft, u, B, K, V, lp_target, accept, n_acc,
+                                            accept_bits, workspace, workspace_bytes, opt, stream);
         if (rc != ASD_OK) return rc;
         return asd_predictor_stop(lp_target, K, nullptr, K, feat, ldf, stats_col, packed_w, in_dim, hidden,
                                   risk_adjustment, n_obs, alpha, beta, p_hist, C, lam, L, stage_idx, prefix_rule, theta, B,
                                   score, k_star, stop, thr_stop, stats, stream);
     }
-    VerifyParams p{};
     p.logits = logits; p.ld_row = ld_row; p.tok = tok; p.lp_d = lp_draft; p.u = u;
     p.B = B; p.K = K; p.V = V; p.v_offset = 0;
     p.lp_t = lp_target; p.accept = accept; p.n_acc = n_acc; p.bits = accept_bits;
-    p.msg = nullptr; p.mode = 0; p.fused = 1; p.scale2 = kLog2e;
+    p.msg = nullptr; p.mode = 0; p.fused = 1;
     FusedParams& e = p.epi;
     e.lp = nullptr; e.ld_lp = K; e.n_valid = nullptr; e.K = K;
     e.feat = feat; e.ldf = ldf; e.stats_col = stats_col;
@@ -739,8 +841,28 @@ ASD_EXPORT int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld
     e.p_hist = p_hist; e.C = C; e.lam = lam; e.L = L; e.stage_idx = stage_idx; e.prefix = prefix_rule ? 1 : 0;
     e.theta = theta; e.B = B;
     e.score = score; e.k_star = k_star; e.stop = stop; e.thr_stop = thr_stop; e.stats = stats;
-    Geometry g{1, 0, 0, 1};   // one workgroup per row; threads / tile size from the heuristic (same as the plain call)
     return launch_verify(p, dtype, workspace, workspace_bytes, stream, g);
+}
+
+ASD_EXPORT int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,
+                                       const float* lp_draft, const float* u, int B, int K, int V, float* lp_target,
+                                       uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits, void* workspace,
+                                       size_t workspace_bytes, const float* feat, int64_t ldf, int stats_col,
+                                       const float* packed_w, int in_dim, int hidden, int risk_adjustment, int64_t n_obs,
+                                       double alpha, double beta, double* p_hist, const double* C, double lam, int L,
+                                       int stage_idx, int prefix_rule, const double* theta, float* score,
+                                       int32_t* k_star, uint8_t* stop, uint8_t* thr_stop, double* stats, void* stream) {
+    return asd_verify_accept_fused_ex(logits, dtype, ld_row, tok, lp_draft, u, B, K, V, lp_target, accept, n_acc,
+                                      accept_bits, workspace, workspace_bytes, feat, ldf, stats_col, packed_w, in_dim,
+                                      hidden, risk_adjustment, n_obs, alpha, beta, p_hist, C, lam, L, stage_idx,
+                                      prefix_rule, theta, score, k_star, stop, thr_stop, stats, nullptr, stream);
+}
+
+/* tests only: the workgroup with linear index row * S + split (S = splits of the launch) does not publish its hand-off
+ * slot in the following launches (its row / sequence must come back poisoned, never silently wrong); -1 = off. */
+ASD_EXPORT int asd_debug_verify_withhold(int index) {
+    asd::g_debug_withhold = index < 0 ? -1 : index;
+    return ASD_OK;
 }
 
 ASD_EXPORT int asd_verify_accept(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,

@@ -55,6 +55,21 @@ class HipOps:
         r = self.K.verify_accept(logits, tok, lp_d, u, ws, inv_temperature=inv_temperature)
         return r.lp_target, r.accept, r.n_acc, r.accept_bits
 
+    def verify_stop(self, logits, tok, lp_d, u, inv_temperature, pred, feat, p_hist, stage_idx, costs, lam,
+                    risk_adjustment=True, n_obs=100, alpha=1.0, beta=1.0, stats_col=5):
+        """ONE launch per tier step (asd_verify_accept_fused_ex): verify + accept, then -- inside the same kernel, by the
+        wave that completes each sequence -- statistics of the K target log-probs -> predictor -> Bayes -> DP rule
+        (pipeline.py:225-261).  Returns ((lp_t, accept, n_acc, bits), (score, k_star, p_hist)); p_hist is updated in
+        place.  Bit-identical to verify_accept followed by predictor_stop (tests/test_gpu_predictor.py)."""
+        B, K = tok.shape
+        ws = self._workspace(B, K, logits.shape[-1], logits.dtype, logits.device)
+        packed, in_dim, hidden = pred
+        v, r = self.K.verify_accept_fused(logits, tok, lp_d, u, ws, feat, packed, in_dim, hidden, stage_idx=stage_idx,
+                                          L=p_hist.shape[1], stats_col=stats_col, risk_adjustment=risk_adjustment, n_obs=n_obs,
+                                          alpha=alpha, beta=beta, p_hist=p_hist, Cc=costs, lam=lam,
+                                          inv_temperature=inv_temperature)
+        return (v.lp_target, v.accept, v.n_acc, v.accept_bits), (r.score, r.k_star, p_hist)
+
     def lse_partial(self, logits_shard, tok, v_offset, inv_temperature: float = 1.0):
         B, K = tok.shape
         ws = self._workspace(B, K, logits_shard.shape[-1], logits_shard.dtype, logits_shard.device)

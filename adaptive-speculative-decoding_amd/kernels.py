@@ -428,9 +428,9 @@ def verify_accept_fused(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch
                         alpha: float = 1.0, beta: float = 1.0, p_hist: Optional[torch.Tensor] = None,
                         Cc: Optional[torch.Tensor] = None, lam: float = 1.0, prefix_rule: bool = False,
                         theta: Optional[torch.Tensor] = None, want_stats: bool = False,
-                        out: Optional[VerifyResult] = None) -> Tuple[VerifyResult, StopResult]:
-    """N1, second form: verify + accept + predictor/stop epilogue in ONE call (one launch when the shape is
-    covered in-kernel, two otherwise; see asd_verify_accept_fused in include/asd_hip.h)."""
+                        out: Optional[VerifyResult] = None, inv_temperature: float = 1.0) -> Tuple[VerifyResult, StopResult]:
+    """N1, second form: verify + accept + predictor/stop epilogue in ONE call (one launch for the reference's
+    64->32->1 predictor at any batch size, two for other predictor shapes; asd_verify_accept_fused_ex in include/asd_hip.h)."""
     Bv, K = tok.shape
     V, ld, ptr = _logits_2d(logits, Bv, K)
     dev = logits.device
@@ -445,7 +445,8 @@ def verify_accept_fused(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch
     stop = torch.empty((Bv,), dtype=torch.uint8, device=dev) if dp else None
     thr = torch.empty((Bv,), dtype=torch.uint8, device=dev) if theta is not None else None
     stats = torch.empty((Bv, 5), dtype=torch.float64, device=dev) if want_stats else None
-    rc = _lib().asd_verify_accept_fused(
+    opt = B.verify_options(inv_temperature)
+    rc = _lib().asd_verify_accept_fused_ex(
         ptr, _DTYPE_CODE[logits.dtype], ld, _dev(tok, "tok", torch.int32), _dev(lp_draft, "lp_draft", torch.float32),
         _dev(u, "u", torch.float32), Bv, K, V, out.lp_target.data_ptr(), out.accept.data_ptr(), out.n_acc.data_ptr(),
         out.accept_bits.data_ptr(), workspace.buf.data_ptr(), workspace.bytes,
@@ -454,8 +455,8 @@ def verify_accept_fused(logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch
         float(beta), _opt(p_hist, "p_hist", torch.float64), _opt(Cc, "C", torch.float64), float(lam), L, stage_idx,
         int(bool(prefix_rule)), _opt(theta, "theta", torch.float64), score.data_ptr(),
         None if k_star is None else k_star.data_ptr(), None if stop is None else stop.data_ptr(),
-        None if thr is None else thr.data_ptr(), None if stats is None else stats.data_ptr(), _stream())
-    B.check("asd_verify_accept_fused", rc)
+        None if thr is None else thr.data_ptr(), None if stats is None else stats.data_ptr(), C.addressof(opt), _stream())
+    B.check("asd_verify_accept_fused_ex", rc)
     return out, StopResult(score, k_star, stop, thr, stats)
 
 
@@ -514,8 +515,10 @@ class DraftSampler:
 
     def __init__(self, B_: int, V: int, dtype: torch.dtype = torch.bfloat16, device: Optional[torch.device] = None):
         self.B, self.V, self.dtype = B_, V, dtype
+        # mailboxes of the workgroups a row is spread over (B <= 128): zeroed ONCE, handed back empty by every call
         self.bytes = int(_lib().asd_draft_sample_workspace_bytes(B_, V, _DTYPE_CODE[dtype]))
         self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device or torch.device("cuda"))
+        B.check("asd_workspace_init", _lib().asd_workspace_init(self.buf.data_ptr(), self.bytes, _stream()))
 
     def __call__(self, logits: torch.Tensor, r: torch.Tensor, inv_temperature: float = 1.0, top_p: float = 1.0,
                  out: Optional[DraftDraw] = None) -> DraftDraw:

@@ -233,6 +233,13 @@ class LogitsHead:
         K = tok.shape[1]
         return self.ops.verify_accept(self._logits[:, :K].contiguous(), tok, lp_d, u, inv_temperature=inv_t)
 
+    def score_and_stop(self, hid, tok, lp_d, u, inv_t, **stop):
+        """The tier step's ONE hot-path launch: verify + accept + the predictor / Bayes / DP epilogue inside the same
+        kernel (ops.verify_stop -> asd_verify_accept_fused_ex)."""
+        self._logits = self.m.lm_head(hid) * self.m.logit_scale
+        K = tok.shape[1]
+        return self.ops.verify_stop(self._logits[:, :K].contiguous(), tok, lp_d, u, inv_t, **stop)
+
     def draw_rows(self, sel: torch.Tensor, j: torch.Tensor) -> torch.Tensor:
         """Target logits row j[i] of local sequence sel[i] -> [m, V]."""
         return self._logits[sel, j].contiguous()
@@ -356,13 +363,19 @@ class VerifyRole:
         self._r = torch.rand((B,), generator=self.gen, device=dev)
         lp_d = dm.lp_d[idx].contiguous()
         tok_i = tok_i.contiguous()
-        lp_t, accept, n_acc, bits = self.head.score(hid, tok_i, lp_d, u, self.inv_t)
         # stop rule: p_hist columns < s from the tiers below, column s from this tier's log-probs, priors 1.0 above
         ph = torch.ones((n, self.L), dtype=torch.float64, device=dev)
         ph[:, :self.s] = p_prev[idx, :self.s]
-        score, k_star, ph = self.ops.predictor_stop(self.pred, lp_t.contiguous(), self.feat[idx].contiguous(), ph, self.s,
-                                                    self.costs, cfg.lambda_value, cfg.risk_adjustment, cfg.n_obs,
-                                                    cfg.risk_alpha, cfg.risk_beta, cfg.stats_col)
+        stop_args = dict(pred=self.pred, feat=self.feat[idx].contiguous(), p_hist=ph, stage_idx=self.s, costs=self.costs,
+                         lam=cfg.lambda_value, risk_adjustment=cfg.risk_adjustment, n_obs=cfg.n_obs, alpha=cfg.risk_alpha,
+                         beta=cfg.risk_beta, stats_col=cfg.stats_col)
+        if hasattr(self.head, "score_and_stop"):            # materialised logits: verify + stop rule in ONE launch
+            (lp_t, accept, n_acc, bits), (score, k_star, ph) = self.head.score_and_stop(hid, tok_i, lp_d, u, self.inv_t, **stop_args)
+        else:                                               # hidden-state heads (fused GEMM, vocabulary shards): two launches
+            lp_t, accept, n_acc, bits = self.head.score(hid, tok_i, lp_d, u, self.inv_t)
+            score, k_star, ph = self.ops.predictor_stop(self.pred, lp_t.contiguous(), stop_args["feat"], ph, self.s,
+                                                        self.costs, cfg.lambda_value, cfg.risk_adjustment, cfg.n_obs,
+                                                        cfg.risk_alpha, cfg.risk_beta, cfg.stats_col)
         stop = torch.ones((n,), dtype=torch.bool, device=dev) if self.last else (k_star <= self.s)
         z = torch.zeros((B,), dtype=torch.int32, device=dev)
         v = Verdict(z.index_put((idx,), torch.ones((n,), dtype=torch.int32, device=dev)),

@@ -46,7 +46,7 @@ class SpeculativeVerifier:
     def __init__(self, batch: int, draft_len: int, vocab: int, *, logits_dtype: torch.dtype = torch.bfloat16,
                  stage_costs: Sequence[float] = (1.0, 4.5, 10.0), lambda_value: float = 1.0,
                  risk_adjustment: bool = True, risk_alpha: float = 1.0, risk_beta: float = 1.0, n_obs: int = 100,
-                 predictor=None, stats_col: int = 5, prefix_rule: bool = False, fused: bool = False, device=None):
+                 predictor=None, stats_col: int = 5, prefix_rule: bool = False, fused: bool = True, device=None):
         if draft_len > 64:
             raise ValueError("draft_len must be <= 64 (one ballot word per sequence)")
         self.B, self.Kd, self.V = batch, draft_len, vocab
@@ -57,7 +57,7 @@ class SpeculativeVerifier:
         self.lam, self.risk = float(lambda_value), bool(risk_adjustment)
         self.alpha, self.beta, self.n_obs = float(risk_alpha), float(risk_beta), int(n_obs)
         self.stats_col, self.prefix = stats_col, bool(prefix_rule)
-        self.fused = bool(fused)          # one launch per step (asd_verify_accept_fused) instead of two
+        self.fused = bool(fused)          # one launch per step (asd_verify_accept_fused_ex; default) instead of two
         self.inv_temperature = 1.0        # sampling temperature of the tier pair, fused into the verify pass
         self.p_hist = torch.ones((batch, self.L), dtype=torch.float64, device=self.device)
         self.sampler = K.ResidualSampler(batch, vocab, logits_dtype, self.device)   # commit step (asd_residual_sample_ex)
@@ -110,13 +110,13 @@ class SpeculativeVerifier:
 
     def step(self, logits: torch.Tensor, tok: torch.Tensor, lp_draft: torch.Tensor, u: torch.Tensor,
              feat: Optional[torch.Tensor] = None, stage_idx: int = 0, out: Optional[K.VerifyResult] = None) -> StepResult:
-        """One verify + stop decision for the whole batch: two launches (one with fused=True), nothing synchronises."""
-        if self.fused and self.packed is not None and feat is not None and self.inv_temperature == 1.0:
+        """One verify + stop decision for the whole batch: ONE launch (two with fused=False), nothing synchronises."""
+        if self.fused and self.packed is not None and feat is not None:
             v, s = K.verify_accept_fused(logits, tok, lp_draft, u, self.ws, feat, self.packed, self.in_dim, self.hidden,
                                          stage_idx=stage_idx, L=self.L, stats_col=self.stats_col,
                                          risk_adjustment=self.risk, n_obs=self.n_obs, alpha=self.alpha, beta=self.beta,
                                          p_hist=self.p_hist[: tok.shape[0]], Cc=self.costs, lam=self.lam,
-                                         prefix_rule=self.prefix, out=out)
+                                         prefix_rule=self.prefix, out=out, inv_temperature=self.inv_temperature)
             return StepResult(v, s)
         v = self.verify(logits, tok, lp_draft, u, out)
         return StepResult(v, self._stop(v, tok, feat, stage_idx))

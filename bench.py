@@ -198,7 +198,7 @@ def _timed_ops(torch):
             self.events = {}
             return out
 
-    for name in ("verify_accept", "lm_head_verify", "lm_head_partial", "accept_from_partials", "predictor_stop",
+    for name in ("verify_accept", "verify_stop", "lm_head_verify", "lm_head_partial", "accept_from_partials", "predictor_stop",
                  "draft_sample", "residual_sample", "commit_step"):
         def wrap(name=name):
             base = getattr(HipOps, name)
@@ -780,9 +780,11 @@ def main():
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--verify-only", action="store_true", help="skip the predictor/stop epilogue launch")
-    ap.add_argument("--fused", action="store_true",
-                    help="one launch per step: asd_verify_accept_fused runs the epilogue inside the verify kernel's last "
-                         "arriver (N1 second form).  Not the default: it lengthens the verify kernel's tail")
+    ap.add_argument("--two-launch", action="store_true",
+                    help="the step as two launches: asd_verify_accept_ex + asd_predictor_stop (the default until round 2).  The "
+                         "default step is ONE launch: asd_verify_accept_fused_ex runs the epilogue inside the verify kernel, by "
+                         "the wave that completes each sequence (N1 second form)")
+    ap.add_argument("--fused", action="store_true", help=argparse.SUPPRESS)      # the default since round 3; kept for old scripts
     ap.add_argument("--mode", choices=["graph", "eager", "overlap"], default="graph",
                     help="graph: runs of steps captured in one hipGraph on one stream (default; falls back to eager if "
                          "capture fails); eager: plain launches; overlap: epilogue forked to a side stream inside the "
@@ -814,6 +816,7 @@ def main():
     ap.add_argument("--launch-timeout", type=float, default=3000.0,
                     help="--gpus N started without torch.distributed.run: seconds after which the spawned ranks are ended")
     args = ap.parse_args()
+    args.fused = not (args.two_launch or args.verify_only)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher BEFORE anything initialises the GPU (torch is not imported yet)
         sys.exit(_spawn_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
@@ -1019,6 +1022,20 @@ def main():
         runs.append(e0.elapsed_time(e1) / reps)
     kern_mean_ms = sum(runs) / len(runs)
     kern_min_ms = min(runs)
+    # the same measurement for the kernel the DEFAULT step launches (the FUSED instantiation: verify + in-kernel epilogue)
+    fused_runs = []
+    if args.fused:
+        for i in range(2000):
+            fused_step(bufs[i % nbuf])
+        torch.cuda.synchronize()
+        for _ in range(5):
+            barrier()
+            e0.record()
+            for i in range(reps):
+                fused_step(bufs[i % nbuf])
+            e1.record()
+            torch.cuda.synchronize()
+            fused_runs.append(e0.elapsed_time(e1) / reps)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -1051,6 +1068,21 @@ def main():
                                              o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(),
                                              o.accept_bits.data_ptr(), ows.buf.data_ptr(), ows.bytes,
                                              torch.cuda.current_stream().cuda_stream)
+            ofeat = feat[:1].expand(oB, 64).contiguous()
+            oph = torch.ones((oB, N_STAGES), dtype=torch.float64, device=device)
+            osc = torch.empty((oB,), dtype=torch.float32, device=device)
+            oks = torch.empty((oB,), dtype=torch.int32, device=device)
+            ost = torch.empty((oB,), dtype=torch.uint8, device=device)
+
+            def ofused(buf):
+                o = buf["out"]
+                return lib.asd_verify_accept_fused(buf["logits"].data_ptr(), 1, oV, buf["tok"].data_ptr(),
+                                                   buf["lp_d"].data_ptr(), buf["u"].data_ptr(), oB, oK, oV,
+                                                   o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(),
+                                                   o.accept_bits.data_ptr(), ows.buf.data_ptr(), ows.bytes, ofeat.data_ptr(), 64, 5,
+                                                   packed.data_ptr(), 64, 32, 1, 100, 1.0, 1.0, oph.data_ptr(), Cc.data_ptr(), 1.0,
+                                                   N_STAGES, 0, 0, None, osc.data_ptr(), oks.data_ptr(), ost.data_ptr(), None, None,
+                                                   torch.cuda.current_stream().cuda_stream)
             ob = algorithmic_bytes(oB, oK, oV)
             # settle for ~60 ms of launches (clock / memory power state ramp after the allocation gap: a short kernel
             # needs thousands of launches for that, 300 left the B=8 figure 30 % above its steady state)
@@ -1058,35 +1090,44 @@ def main():
                 overify(obufs[i % onb])
             # a B=8 launch (8 us) is shorter than a Python ctypes call: time replays of a hipGraph of the launches
             # (same kernels, same rotating buffers), eager only if capture is refused (e.g. under a profiler)
-            og, per = None, 24      # 24 launches per graph whatever the buffer count: a replay boundary costs ~10 us,
+            per = 24                # 24 launches per graph whatever the buffer count: a replay boundary costs ~10 us,
                                     # 6 % of a graph of three B=128 launches
-            try:
-                torch.cuda.synchronize()
-                og = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(og):
-                    for i in range(per):
-                        overify(obufs[i % onb])
-                og.replay()
-                torch.cuda.synchronize()
-            except Exception:  # noqa: BLE001
+
+            def time_launches(fn):
                 og = None
-            oreps = 10 if og is not None else 200
-            oruns = []
-            for _ in range(5):
-                e0.record()
-                for i in range(oreps):
-                    if og is not None:
-                        og.replay()
-                    else:
-                        overify(obufs[i % onb])
-                e1.record()
-                torch.cuda.synchronize()
-                oruns.append(e0.elapsed_time(e1) / (oreps * (per if og is not None else 1)))
-            del og
+                try:
+                    torch.cuda.synchronize()
+                    og = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(og):
+                        for i in range(per):
+                            fn(obufs[i % onb])
+                    og.replay()
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    og = None
+                oreps = 10 if og is not None else 200
+                oruns = []
+                for _ in range(5):
+                    e0.record()
+                    for i in range(oreps):
+                        if og is not None:
+                            og.replay()
+                        else:
+                            fn(obufs[i % onb])
+                    e1.record()
+                    torch.cuda.synchronize()
+                    oruns.append(e0.elapsed_time(e1) / (oreps * (per if og is not None else 1)))
+                del og
+                return oruns
+            oruns = time_launches(overify)
             oms = sum(oruns) / len(oruns)
+            fruns = time_launches(ofused)
+            fms = sum(fruns) / len(fruns)
             others[name] = {"batch": oB, "draft_len": oK, "vocab": oV, "algorithmic_bytes": ob, "kernel_ms_mean": oms,
                             "kernel_ms_runs": oruns, "launch": "hipGraph replays of back-to-back launches", "achieved_GBs": ob / (oms * 1e-3) / 1e9,
-                            "frac_of_8TBs": ob / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                            "frac_of_8TBs": ob / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "step_one_launch_ms_mean": fms, "step_one_launch_ms_runs": fruns,
+                            "step_note": "asd_verify_accept_fused: verify + in-kernel predictor / Bayes / DP epilogue, one launch"}
             del obufs, ows
             torch.cuda.empty_cache()
 
@@ -1136,7 +1177,7 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}; step = "
-                                   + ("asd_verify_accept_fused (epilogue inside the verify launch)" if args.fused else
+                                   + ("asd_verify_accept_fused_ex: ONE launch (verify + accept + in-kernel stats->MLP->Bayes->DP epilogue)" if args.fused else
                                       "asd_verify_accept" + ("" if args.verify_only else
                                                              " + asd_predictor_stop (stats->MLP->Bayes->DP)")),
                        "batch_per_gpu": B, "draft_len": K, "vocab": V, "accumulate": "f32 (epilogue f64)",
@@ -1157,6 +1198,15 @@ def main():
                                    "(rotating buffers) right after the timed region; includes inter-kernel gaps",
                          "note": "event PAIRS around single launches add 5-15 us each on this stack (measured in round 1) and are not used"},
         }
+        if fused_runs:
+            fm = sum(fused_runs) / len(fused_runs)
+            out["roofline"]["step_kernel"] = {
+                "kernel": "asd::k_verify<..., FUSED> (verify + in-kernel predictor / Bayes / DP epilogue; the default step's one launch)",
+                "kernel_ms_mean": fm, "kernel_ms_runs": fused_runs, "achieved": bytes_per_launch / (fm * 1e-3) / 1e9,
+                "frac": bytes_per_launch / (fm * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "same algorithmic bytes; the duration includes the epilogue the two-launch step runs as a second kernel "
+                        "(asd_predictor_stop, ~4 us + launch gap).  `frac` above is the streaming kernel named by the north star "
+                        "(plain instantiation, what --two-launch runs)"}
         if others:
             out["roofline"]["other_workloads_kernel_only"] = others
         if loop_rec is not None:

@@ -329,20 +329,36 @@ int asd_residual_sample_ex(const void* t_logits, int64_t ld_t, const void* d_log
  *   lp[b]  = log q(tok[b])                                       (the lp_draft the verify step needs; may be NULL)
  *   nucleus_logit[b] = x*_b (-inf without truncation; may be NULL): with it asd_residual_sample_ex reconstructs q exactly.
  * logits: [B rows][V] of `dtype`, rows ld ELEMENTS apart, 16-byte aligned, a whole number of 16-byte vectors.
- * Rows must not contain NaN / +inf.  One launch, one 1024-lane workgroup per row (the row stays in its CU's L2 / LDS
- * reach); V*sizeof(elem) <= 2 MiB.  workspace: unused since 0.2 (asd_draft_sample_workspace_bytes returns 256; may be NULL).
+ * Rows must not contain NaN / +inf.  ONE launch; V*sizeof(elem) <= 2 MiB.
+ * Geometry: up to 128 rows, every row is spread over G = 2 ... 32 workgroups (~one per compute unit) that keep their part
+ * of the row in registers and meet through single-writer / single-reader mailbox words in `workspace`; more rows, or a NULL /
+ * short workspace: one streaming 1024-lane workgroup per row.  The per-tile partial sums are canonical and folded in a
+ * fixed order, so tok / lp / nucleus_logit do NOT depend on the geometry (lp and nucleus_logit bit for bit; the token
+ * wherever the draw is more than a float rounding away from a tile boundary of the CDF).
+ * workspace: asd_draft_sample_workspace_bytes(B,V,dtype) bytes (~25 MB), 256-byte aligned, zero-initialised ONCE with
+ * asd_workspace_init; every call hands it back all-zero, so one workspace serves any number of stream-ordered calls of any
+ * B' <= B (two calls that may run concurrently need two).  A hand-off that never arrives (bounded wait) POISONS the row --
+ * tok = -1, lp = nucleus_logit = NaN -- it is never guessed.
  * ---------------------------------------------------------------------------------------- */
 size_t asd_draft_sample_workspace_bytes(int B, int V, int dtype);
 int asd_draft_sample(const void* logits, int64_t ld, int dtype, const float* r /*[B]*/, int B, int V,
                      float inv_temperature, float top_p, int32_t* tok /*[B] out*/, float* lp /*[B] out, may be NULL*/,
                      float* nucleus_logit /*[B] out, may be NULL*/, void* workspace, size_t workspace_bytes, void* stream);
+/* Test hook (host state; no reference counterpart): force the workgroups per row of the following asd_draft_sample calls
+ * (1, 2, 4 ... 32; -1 = the one-workgroup streaming form; 0 = heuristic).  Results must not depend on it. */
+int asd_debug_draft_groups(int groups);
 
 /* N1, second form: asd_verify_accept with the epilogue of asd_predictor_stop run INSIDE the same
- * launch by the workgroup that completes each sequence (lp = the kernel's own lp_target, all K
- * positions valid).  One launch per tier step instead of two.  The in-kernel form covers the
- * reference's 64->32->1 predictor, K <= 32 and B*K >= the number of CUs; any other shape is served
- * by the same call as two launches with identical results.  Parameters: those of
- * asd_verify_accept followed by those of asd_predictor_stop (without lp / n_valid / K / B). */
+ * launch by the wave that completes each sequence (lp = the kernel's own lp_target, all K
+ * positions valid).  ONE launch per tier step instead of two, at every batch size: with one workgroup
+ * per row (B*K >= CUs) every row hands its lp_t to the sequence's finisher through a self-tagging
+ * workspace slot; with split rows (B*K < CUs, e.g. B = 8) the finisher wave already holds all K lp_t.
+ * The in-kernel form covers the reference's 64->32->1 predictor (src/minimal_adaptive_decoder.py:38-49);
+ * any other predictor shape is served by the same call as two launches with identical results
+ * (bit-identical: tests/test_gpu_predictor.py).  Parameters: those of asd_verify_accept followed by those
+ * of asd_predictor_stop (without lp / n_valid / K / B); _ex adds asd_verify_options (inv_temperature:
+ * the tiers verify at T = 0.7, pipeline.py:94).  Replaces the per-stage sequence
+ * predictor.predict -> bayesian_adjustment -> optimal_stopping_rule of src/serving/pipeline.py:225-261. */
 int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld_row,
                             const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
                             float* lp_target, uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits,
@@ -354,6 +370,24 @@ int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld_row,
                             const double* theta,
                             float* score, int32_t* k_star, uint8_t* stop, uint8_t* thr_stop, double* stats,
                             void* stream);
+int asd_verify_accept_fused_ex(const void* logits, int dtype, int64_t ld_row,
+                               const int32_t* tok, const float* lp_draft, const float* u, int B, int K, int V,
+                               float* lp_target, uint8_t* accept, int32_t* n_acc, uint64_t* accept_bits,
+                               void* workspace, size_t workspace_bytes,
+                               const float* feat, int64_t ldf, int stats_col,
+                               const float* packed_w, int in_dim, int hidden,
+                               int risk_adjustment, int64_t n_obs, double alpha, double beta,
+                               double* p_hist, const double* C, double lam, int L, int stage_idx, int prefix_rule,
+                               const double* theta,
+                               float* score, int32_t* k_star, uint8_t* stop, uint8_t* thr_stop, double* stats,
+                               const asd_verify_options* opt /*host, may be NULL*/, void* stream);
+
+/* Test hook (host state, not thread-safe; no reference counterpart): in the verify launches that follow, the workgroup
+ * with linear index row * S + split (S = the launch's splits per row) does not publish its hand-off slot.  The kernel's
+ * bounded wait must then POISON the affected outputs -- lp_target = NaN and accept = 0 for the row (split rows), score =
+ * NaN / k_star = L - 1 / stop = 0 for the sequence (in-kernel epilogue) -- never return a plausible wrong value.
+ * index < 0 switches the hook off. */
+int asd_debug_verify_withhold(int index);
 
 #ifdef __cplusplus
 }

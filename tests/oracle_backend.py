@@ -136,6 +136,12 @@ class OracleOps:
         p_hist.copy_(torch.from_numpy(hist))
         return torch.from_numpy(score), torch.from_numpy(k_star), p_hist
 
+    def verify_stop(self, logits, tok, lp_d, u, inv_temperature, pred, feat, p_hist, stage_idx, costs, lam,
+                    risk_adjustment=True, n_obs=100, alpha=1.0, beta=1.0, stats_col=5):
+        v = self.verify_accept(logits, tok, lp_d, u, inv_temperature)
+        return v, self.predictor_stop(pred, v[0], feat, p_hist, stage_idx, costs, lam, risk_adjustment, n_obs, alpha, beta,
+                                      stats_col)
+
     def draft_sample(self, logits, r, inv_temperature=1.0, top_p=1.0):
         store, dt = _np_store(logits)
         B, V = store.shape

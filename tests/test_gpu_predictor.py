@@ -146,11 +146,14 @@ def test_fused_epilogue_without_stats(golden, K_):
     assert r.k_star is None and r.thr_stop is None
 
 
-@pytest.mark.parametrize("B,K,V", [(32, 8, 30000), (64, 8, 20000), (40, 32, 5000), (8, 8, 30000), (33, 7, 9999)])
-def test_in_kernel_epilogue_equals_two_launches(golden, K_, B, K, V):
-    """asd_verify_accept_fused (N1 second form) == asd_verify_accept followed by asd_predictor_stop,
-    bit for bit, both where the epilogue runs inside the verify launch (B*K >= CUs, K <= 32) and where
-    the call falls back to two launches (B*K < CUs)."""
+@pytest.mark.parametrize("B,K,V,T", [(32, 8, 30000, 1.0), (64, 8, 20000, 0.7), (40, 32, 5000, 1.0), (8, 8, 30000, 1.0),
+                                     (33, 7, 9999, 0.7), (8, 8, 152064, 0.7), (16, 8, 152064, 1.0), (6, 40, 4000, 0.7),
+                                     (40, 40, 3000, 1.0), (1, 1, 152064, 0.7)])
+def test_in_kernel_epilogue_equals_two_launches(golden, K_, B, K, V, T):
+    """asd_verify_accept_fused_ex (N1 second form) == asd_verify_accept_ex followed by asd_predictor_stop, bit for bit,
+    on every path of the ONE launch: one workgroup per row (B*K >= CUs: each row hands lp_t over through a self-tagging
+    slot), split rows (B*K < CUs, e.g. BASELINE configs[1] B = 8: the finisher wave holds all K lp_t), K > 32 (no
+    ballot-by-atomic), with and without the temperature folded in."""
     import torch
     from tests.helpers import make_verify_case, to_device_logits, assert_verify_matches
     g = golden.npz("predictor.npz")
@@ -163,22 +166,25 @@ def test_in_kernel_epilogue_equals_two_launches(golden, K_, B, K, V):
     Cc = torch.tensor([1.0, 4.5, 10.0], dtype=torch.float64, device="cuda")
     theta = torch.tensor([0.6, 0.4, 0.0], dtype=torch.float64, device="cuda")
     ws = K_.VerifyWorkspace(B, K, V)
+    inv_t = float(np.float32(1.0 / T))
     for rep in range(3):                                          # repeated calls: the hand-off lines are reusable
         ph1 = torch.ones((B, 3), dtype=torch.float64, device="cuda")
         ph2 = ph1.clone()
-        v1 = K_.verify_accept(lg, tok, lp_d, u, ws)
+        v1 = K_.verify_accept(lg, tok, lp_d, u, ws, inv_temperature=inv_t)
         s1 = K_.predictor_stop(feat, packed, 64, 32, stage_idx=0, L=3, lp=v1.lp_target, stats_col=5, risk_adjustment=True,
                                n_obs=120, alpha=1.0, beta=1.5, p_hist=ph1, Cc=Cc, lam=0.8, theta=theta, want_stats=True)
         v2, s2 = K_.verify_accept_fused(lg, tok, lp_d, u, ws, feat, packed, 64, 32, stage_idx=0, L=3, stats_col=5,
                                         risk_adjustment=True, n_obs=120, alpha=1.0, beta=1.5, p_hist=ph2, Cc=Cc, lam=0.8,
-                                        theta=theta, want_stats=True)
+                                        theta=theta, want_stats=True, inv_temperature=inv_t)
         torch.cuda.synchronize()
+        assert int(ws.buf.count_nonzero()) == 0                   # every hand-off word is handed back empty
         for a, b in ((v1.lp_target, v2.lp_target), (v1.accept, v2.accept), (v1.n_acc, v2.n_acc),
                      (v1.accept_bits, v2.accept_bits), (s1.stats, s2.stats), (s1.score, s2.score), (s1.k_star, s2.k_star),
                      (s1.stop, s2.stop), (s1.thr_stop, s2.thr_stop), (ph1, ph2)):
             assert torch.equal(a, b)
     got = dict(lp_t=v2.lp_target.cpu().numpy(), accept=v2.accept.cpu().numpy(), n_acc=v2.n_acc.cpu().numpy(),
                bits=v2.accept_bits.cpu().numpy().view(np.uint64))
-    assert_verify_matches(got, case["ref"])
+    if T == 1.0:
+        assert_verify_matches(got, case["ref"])
     stats = O.logprob_stats(got["lp_t"], None, K)
     assert s2.stats.cpu().numpy().tobytes() == stats.tobytes()

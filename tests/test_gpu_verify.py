@@ -544,3 +544,113 @@ def test_verify_stats_limits(K_):
     r, mx, ent = K_.verify_accept_stats(lg, torch.zeros((B, K), dtype=torch.int32, device="cuda"), z, z + 0.5, ws, want_entropy=False)
     torch.cuda.synchronize()
     np.testing.assert_allclose(mx.cpu().numpy(), -np.log(V), atol=1e-5)      # a flat row: every log-prob is -ln V
+
+
+def _fused_args(K_, B, seed=5):
+    import torch
+    from tests.conftest import load_npz
+    g = load_npz("predictor.npz")
+    packed = K_.pack_mlp_weights(g["w1"], g["b1"], g["w2"], g["b2"])
+    rng = np.random.default_rng(seed)
+    feat = torch.from_numpy((rng.standard_normal((B, 64)) * 0.3).astype(np.float32)).cuda()
+    Cc = torch.tensor([1.0, 4.5, 10.0], dtype=torch.float64, device="cuda")
+    return feat, packed, Cc
+
+
+def test_workspace_is_all_zero_after_every_call_form_and_shared_across_shapes(K_):
+    """The workspace invariant: tickets, ballot words, lp slots and granule slots are zero between
+    calls, so calls of DIFFERENT shapes may share one workspace in stream order.  The layout depends on B (the granule
+    regions start behind B ticket blocks): a fused call at B = 32 followed by a split call at B = 8 puts granule regions
+    where the lp hand-off slots were -- a stale non-zero word there would be taken for a published granule."""
+    import torch
+    V = 30000
+    big = make_verify_case(32, 8, V, O.DT_BF16, seed=41)
+    small = make_verify_case(8, 8, V, O.DT_BF16, seed=42)
+    dev = {}
+    for name, c in (("big", big), ("small", small)):
+        dev[name] = (to_device_logits(c["logits"], c["dtype"]).view(c["B"], c["K"], V),) + tuple(
+            torch.from_numpy(c[k]).cuda() for k in ("tok", "lp_d", "u"))
+    ws = K_.VerifyWorkspace(32, 8, V)
+    fresh = K_.verify_accept(*dev["small"], K_.VerifyWorkspace(8, 8, V))
+    torch.cuda.synchronize()
+
+    def clean():
+        torch.cuda.synchronize()
+        assert int(ws.buf.count_nonzero()) == 0
+
+    def check(r, c):
+        assert np.array_equal(r.accept.cpu().numpy(), c["ref"]["accept"]) and np.array_equal(r.n_acc.cpu().numpy(), c["ref"]["n_acc"])
+
+    feat32, packed, Cc = _fused_args(K_, 32)
+    feat8 = feat32[:8].contiguous()
+    for rep in range(3):
+        ph = torch.ones((32, 3), dtype=torch.float64, device="cuda")
+        v, s = K_.verify_accept_fused(*dev["big"], ws, feat32, packed, 64, 32, stage_idx=0, L=3, p_hist=ph, Cc=Cc, lam=0.8)
+        clean(); check(v, big)                                                           # fused, one workgroup per row
+        r = K_.verify_accept(*dev["small"], ws)                                          # split rows, B = 8, same workspace
+        clean(); check(r, small)
+        assert torch.equal(r.lp_target, fresh.lp_target) and torch.equal(r.accept_bits, fresh.accept_bits)
+        ph8 = torch.ones((8, 3), dtype=torch.float64, device="cuda")
+        v8, s8 = K_.verify_accept_fused(*dev["small"], ws, feat8, packed, 64, 32, stage_idx=0, L=3, p_hist=ph8, Cc=Cc, lam=0.8)
+        clean(); check(v8, small)                                                        # fused, split rows
+        assert torch.equal(v8.lp_target, fresh.lp_target)
+        r = K_.verify_accept(*dev["big"], ws)                                            # plain, one workgroup per row
+        clean(); check(r, big)
+        r = K_.verify_accept(*dev["big"], ws, splits=3)                                  # forced split at rows >= CUs
+        clean(); check(r, big)
+        K_.verify_accept_stats(*dev["big"], ws)
+        clean()
+        K_.lse_partial(dev["small"][0], dev["small"][1], 0, ws)
+        clean()
+        K_.lse_partial(dev["big"][0], dev["big"][1], 0, ws)
+        clean()
+
+
+@pytest.mark.parametrize("form", ["split", "fused_rows", "fused_split"])
+def test_a_withheld_hand_off_poisons_the_result_instead_of_folding_a_zero(K_, form):
+    """asd_debug_verify_withhold makes one workgroup skip its hand-off store: the finisher's bounded wait must end in
+    NaN / reject (split rows) or score = NaN, k* = L - 1, stop = 0 (in-kernel epilogue) for THAT row / sequence only,
+    and leave the workspace clean for the next call."""
+    import torch
+    V = 40000                                               # wide enough for ceil(CUs / rows) = 4 slices of >= one tile per wave
+    B = 32 if form == "fused_rows" else 8
+    c = make_verify_case(B, 8, V, O.DT_BF16, seed=B + 7)
+    lg = to_device_logits(c["logits"], c["dtype"]).view(B, 8, V)
+    tok, lp_d, u = (torch.from_numpy(c[k]).cuda() for k in ("tok", "lp_d", "u"))
+    ws = K_.VerifyWorkspace(B, 8, V)
+    feat, packed, Cc = _fused_args(K_, B)
+    lib = K_._lib()
+    cus = K_.device_cu_count()
+    S = 1 if B * 8 >= cus else -(-cus // (B * 8))          # the launcher's split count (rows < CUs: ceil(CUs / rows))
+    bad_b, bad_k = 3, 5
+    row = bad_b * 8 + bad_k
+    try:
+        lib.asd_debug_verify_withhold(row * S + (S - 1))
+        ph = torch.ones((B, 3), dtype=torch.float64, device="cuda")
+        if form == "split":
+            v, s = K_.verify_accept(lg, tok, lp_d, u, ws), None
+        else:
+            v, s = K_.verify_accept_fused(lg, tok, lp_d, u, ws, feat, packed, 64, 32, stage_idx=0, L=3, p_hist=ph, Cc=Cc, lam=0.8)
+        torch.cuda.synchronize()
+    finally:
+        lib.asd_debug_verify_withhold(-1)
+    lp = v.lp_target.cpu().numpy()
+    acc = v.accept.cpu().numpy()
+    others = np.ones((B, 8), bool)
+    if form == "fused_rows":                                # rows finish themselves: only the epilogue lost its input
+        np.testing.assert_allclose(lp, c["ref"]["lp_t64"], atol=1e-5, rtol=1e-6)
+        assert np.array_equal(acc, c["ref"]["accept"])
+    else:
+        others[bad_b, bad_k] = False
+        assert np.isnan(lp[bad_b, bad_k]) and acc[bad_b, bad_k] == 0
+        np.testing.assert_allclose(lp[others], c["ref"]["lp_t64"][others], atol=1e-5, rtol=1e-6)
+        assert np.array_equal(acc[others], c["ref"]["accept"][others])
+        assert int(v.n_acc[bad_b]) <= bad_k
+    if s is not None:
+        sc = s.score.cpu().numpy()
+        assert np.isnan(sc[bad_b]) and int(s.k_star[bad_b]) == 2 and int(s.stop[bad_b]) == 0
+        assert np.isfinite(np.delete(sc, bad_b)).all()
+    assert int(ws.buf.count_nonzero()) == 0
+    again = K_.verify_accept(lg, tok, lp_d, u, ws)         # the hook is off: the same workspace serves a clean call
+    torch.cuda.synchronize()
+    assert np.array_equal(again.accept.cpu().numpy(), c["ref"]["accept"])

@@ -5,7 +5,10 @@ prints, relative to the earliest workgroup start, the distribution of
   t0 start | t1 first batch consumed | t2 stream end | t3 workgroup reduced | t4 before ticket | t5 done.
 Stamp = s_memrealtime (100 MHz => 10 ns ticks).
 
-    python tools/stamp_verify.py [c3|c2|c5] [splits,threads,unroll,nt]
+    python tools/stamp_verify.py [c3|c2|c5] [splits,threads,unroll,nt] [chain] [fused]
+
+`fused`: stamp asd_verify_accept_fused_ex instead (t4 = finisher starts waiting for the hand-off slots, t5 = has them,
+t8 = in-kernel epilogue done).
 """
 import ctypes as C
 import math
@@ -25,6 +28,7 @@ def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
     geom = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 0, 0, -1]
     chain = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    fused = len(sys.argv) > 4 and sys.argv[4] == "fused"
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     lib_path = os.path.join(out, "libasd_hip_stamp.so")
@@ -39,7 +43,7 @@ def main():
     nbuf = max(3, math.ceil(640e6 / (B * Kk * V * 2)))
     ws, bufs = build_inputs(torch, K, B, Kk, V, nbuf, dev, 1234)
     nblk = B * Kk * 64
-    stamps = torch.zeros((nblk * 24,), dtype=torch.int64, device=dev)
+    stamps = torch.zeros((nblk * 32,), dtype=torch.int64, device=dev)
     lib.asd_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     assert lib.asd_debug_set_stamp_buffer(stamps.data_ptr()) == 0
     from asd_amd._binding import verify_options
@@ -48,6 +52,24 @@ def main():
                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     opt = verify_options(1.0, *geom)
     st = torch.cuda.current_stream().cuda_stream
+    if fused:
+        from bench import N_STAGES, STAGE_COSTS, predictor_weights
+        from asd_amd._binding import SIGNATURES
+        plain = fn
+        ff = lib.asd_verify_accept_fused_ex
+        ff.restype, ff.argtypes = SIGNATURES["asd_verify_accept_fused_ex"]
+        packed = K.pack_mlp_weights(*predictor_weights(np), device=dev)
+        feat = torch.from_numpy((np.random.default_rng(7).standard_normal((B, 64)) * 0.3).astype(np.float32)).to(dev)
+        Cc = torch.tensor(STAGE_COSTS, dtype=torch.float64, device=dev)
+        ph = torch.ones((B, N_STAGES), dtype=torch.float64, device=dev)
+        score = torch.empty((B,), dtype=torch.float32, device=dev)
+        ks = torch.empty((B,), dtype=torch.int32, device=dev)
+        stp = torch.empty((B,), dtype=torch.uint8, device=dev)
+
+        def fn(lg, dt, ld, tok, lpd, u, B_, K_, V_, lp, acc, nacc, bits, wsb, wsn, optp, stream):   # noqa: E306
+            return ff(lg, dt, ld, tok, lpd, u, B_, K_, V_, lp, acc, nacc, bits, wsb, wsn, feat.data_ptr(), 64, 5, packed.data_ptr(),
+                      64, 32, 1, 100, 1.0, 1.0, ph.data_ptr(), Cc.data_ptr(), 1.0, N_STAGES, 0, 0, None, score.data_ptr(),
+                      ks.data_ptr(), stp.data_ptr(), None, None, optp, stream)
     res, xcc, waves = [], [], []
     if chain > 1:
         for j in range(600):   # settle clocks like bench.py does
@@ -69,19 +91,22 @@ def main():
             assert rc == 0, rc
         torch.cuda.synchronize()
         raw = stamps.cpu().numpy()
-        grid = B * Kk * (geom[0] if geom[0] > 0 else 1)   # default geometry at rows >= CUs: one workgroup per row
-        s = raw[: grid * 8].reshape(grid, 8)
-        wv = raw[grid * 8: grid * 8 + grid * 16].reshape(grid, 16).astype(np.float64)
+        cus = K.device_cu_count()
+        auto_s = 1 if B * Kk >= cus else min(-(-cus // (B * Kk)), (V * 2) // (8 * 2 * 1024))
+        grid = B * Kk * (geom[0] if geom[0] > 0 else auto_s)   # the launcher's heuristic: one workgroup per row at rows >= CUs
+        s = raw[: grid * 16].reshape(grid, 16)
+        wv = raw[grid * 16: grid * 16 + grid * 16].reshape(grid, 16).astype(np.float64)
         live = s[:, 0] > 0
         s = s[live].astype(np.float64)
         t0 = s[:, 0].min()
-        rel = (s[:, [0, 1, 2, 3, 4, 5, 7]] - t0) / 100.0      # us
+        rel = (s[:, [0, 1, 2, 3, 4, 5, 7, 8]] - t0) / 100.0      # us
         if it >= 2:
             res.append(rel)
             xcc.append(s[:, 6].astype(int))
             waves.append((wv - t0) / 100.0)
     rel = np.concatenate(res)
-    names = ["start", "first batch consumed", "stream end", "wg reduced", "before ticket", "done", "first loads issued"]
+    names = ["start", "first batch consumed", "stream end", "wg reduced", "before ticket / slot wait", "ticket back / slots read",
+             "first loads issued", "in-kernel epilogue done"]
     print(f"workload {wl}, geometry {geom}, chain {chain}, {len(res)} launches, {rel.shape[0] // len(res)} workgroups each; us from first start")
     for i, n in enumerate(names):
         col = rel[:, i]
