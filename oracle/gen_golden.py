@@ -489,6 +489,134 @@ def gen_speculative_sampling():
              margin=np.array(rec["margin"], np.float64).reshape(-1, 3))
 
 
+SPEC_FULL_SEED = 20261004
+
+
+def spec_full_rows(seed: int, case: int, K: int, V: int, scale: float, spread: float, storage: str):
+    """RAW draft rows [K, V] and target rows [K + 1, V] of a full-vocabulary case as f32 values AFTER the storage rounding
+    (bf16 / f16: what a tier's lm_head really hands over), plus the K uniforms the drafted tokens are drawn with --
+    regenerated from (seed, case) by the tests (tests/helpers.py::spec_full_cases)."""
+    rng = np.random.default_rng([seed, case])
+    cand = (rng.standard_normal((K, V)) * float(np.float32(scale))).astype(np.float32)
+    new = np.empty((K + 1, V), np.float32)
+    new[:K] = (cand.astype(np.float64) + rng.standard_normal((K, V)) * float(np.float32(spread))).astype(np.float32)
+    new[K] = (rng.standard_normal(V) * float(np.float32(scale))).astype(np.float32)
+    pick = rng.uniform(0, 1, K).astype(np.float32)
+
+    def rnd(x):
+        if storage == "bf16":
+            return torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+        if storage == "f16":
+            return x.astype(np.float16).astype(np.float32)
+        return x
+    return rnd(cand), rnd(new), pick
+
+
+def gen_speculative_sampling_full():
+    """A5 + the residual draw AT THE SIZE AND SETTINGS THE PATH RUNS AT: V = 152064 (Qwen2.5), rows that
+    went through bf16 / f16 storage, the reference's sampling parameters (generate_training_data.py:110-119: temperature
+    0.7, top_p 0.9).  As in HF's assisted generation the DRAFT scores are warped by TemperatureLogitsWarper(0.7) +
+    TopPLogitsWarper(0.9) (the classes of the installed transformers, called unmodified) before they reach
+    `_speculative_sampling`; the TARGET scores by TemperatureLogitsWarper(0.7) only -- the tiers of this build verify
+    against the target's full softmax(x / T).  Drafted tokens: inverse CDF (vocabulary order) of HF's warped draft
+    distribution against stored uniforms.  `_speculative_sampling` is called unmodified with its uniforms supplied and its
+    multinomial input recorded, exactly as in gen_speculative_sampling.  Stored per case (a few hundred bytes; rows are
+    regenerated from seeds): the drafted tokens, HF's log q(token), the per-row nucleus threshold in RAW score units (the
+    smallest surviving score: what asd_draft_sample reports and asd_residual_sample_ex consumes) with the number of equal
+    scores the warper's sort order dropped, the acceptance uniforms,
+    HF's n_matches, and for three uniforms the inverse-CDF token of HF's p' with its distance to the nearer CDF edge."""
+    import transformers.generation.utils as U
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopPLogitsWarper
+    V, T, TOP_P = 152064, 0.7, 0.9
+    cases = []
+    c = 0
+    for storage in ("bf16", "f16"):
+        for K in (4, 8):
+            for scale, spread in ((3.0, 0.5), (4.0, 1.5), (2.0, 0.1), (6.0, 1.0)):
+                cases.append((c, K, scale, spread, storage))
+                c += 1
+    rec = dict(case=[], K=[], scale=[], spread=[], storage=[], off=[0], u=[], ids=[], lq=[], thr=[], n_keep=[], ties_removed=[], pick_margin=[],
+               n_matches=[], r=[], tok=[], margin=[])
+    rng = np.random.default_rng(SPEC_FULL_SEED)
+    real_rand_like, real_multinomial = torch.rand_like, torch.multinomial
+    for (case, K, scale, spread, storage) in cases:
+        cand, new, pick = spec_full_rows(SPEC_FULL_SEED, case, K, V, scale, spread, storage)
+        cand_w = TopPLogitsWarper(TOP_P)(None, TemperatureLogitsWarper(T)(None, torch.from_numpy(cand.copy())))
+        new_w = TemperatureLogitsWarper(T)(None, torch.from_numpy(new.copy()))
+        keep = torch.isfinite(cand_w).numpy()
+        thr = np.array([cand[k][keep[k]].min() for k in range(K)], np.float32)
+        lq_all = torch.log_softmax(cand_w.double(), dim=-1).numpy()
+        ids = np.empty(K, np.int64)
+        pm = np.empty(K)
+        for k in range(K):
+            q = np.exp(lq_all[k])
+            cum = np.cumsum(q)
+            target = float(pick[k]) * cum[-1]
+            t = int(np.searchsorted(cum, target, side="right"))
+            while t < V - 1 and q[t] <= 0.0:
+                t += 1
+            ids[k] = min(t, V - 1)
+            lo = cum[ids[k] - 1] if ids[k] > 0 else 0.0
+            pm[k] = min(target - lo, cum[ids[k]] - target) / cum[-1]
+        lq = lq_all[np.arange(K), ids]
+        lp = torch.log_softmax(new_w[:K].double(), dim=-1).numpy()[np.arange(K), ids]
+        ratio = lp - lq
+        u = rng.uniform(0, 1, K)
+        for _ in range(100):
+            bad = np.abs(np.log(u) - ratio) < 1e-3
+            if not bad.any():
+                break
+            u[bad] = rng.uniform(0, 1, int(bad.sum()))
+        u = u.astype(np.float32)
+        got = {}
+
+        def fake_rand_like(t, *a, **k):
+            return torch.from_numpy(u.copy()).to(t.dtype).reshape(t.shape)
+
+        def fake_multinomial(p, num_samples=1, **k):
+            got["p"] = p.detach().clone()
+            return torch.zeros((p.shape[0], num_samples), dtype=torch.long)
+
+        torch.rand_like, torch.multinomial = fake_rand_like, fake_multinomial
+        try:
+            _, n = U._speculative_sampling(torch.from_numpy(ids)[None, :], cand_w[None], K, new_w[None], False)
+        finally:
+            torch.rand_like, torch.multinomial = real_rand_like, real_multinomial
+        n = int(n)
+        pp = got["p"][0].double().numpy()
+        cum = np.cumsum(pp)
+        total = cum[-1]
+        for r in rng.uniform(0, 1, 3).astype(np.float32):
+            target = float(r) * total
+            t = int(np.searchsorted(cum, target, side="right"))
+            while t < V - 1 and pp[t] <= 0.0:
+                t += 1
+            t = min(t, V - 1)
+            lo = cum[t - 1] if t > 0 else 0.0
+            rec["r"].append(r)
+            rec["tok"].append(t)
+            rec["margin"].append(min(target - lo, cum[t] - target) / total)
+        rec["case"].append(case); rec["K"].append(K); rec["scale"].append(scale); rec["spread"].append(spread)
+        rec["storage"].append(storage); rec["off"].append(rec["off"][-1] + K)
+        rec["u"].append(u); rec["ids"].append(ids.astype(np.int32)); rec["lq"].append(lq); rec["thr"].append(thr)
+        rec["n_keep"].append(keep.sum(1).astype(np.int32)); rec["pick_margin"].append(pm); rec["n_matches"].append(n)
+        # scores EQUAL to the threshold that the warper's sort order dropped (the kernels keep every tie): rows with such
+        # ties have a slightly different nucleus, so their drafted token / log q are not compared with HF's
+        rec["ties_removed"].append(np.array([int(((cand[k] == thr[k]) & ~keep[k]).sum()) for k in range(K)], np.int32))
+        print(f"  spec_full case {case}: {storage} K={K} scale={scale} spread={spread} nucleus {keep.sum(1).tolist()} "
+              f"ties removed {rec['ties_removed'][-1].tolist()} n_matches {n}")
+    np.savez(os.path.join(OUT, "speculative_sampling_full.npz"), seed=np.int64(SPEC_FULL_SEED), V=np.int32(V), T=np.float32(T),
+             top_p=np.float32(TOP_P), case=np.array(rec["case"], np.int32), K=np.array(rec["K"], np.int32),
+             scale=np.array(rec["scale"], np.float32), spread=np.array(rec["spread"], np.float32),
+             storage=np.array(rec["storage"]), off=np.array(rec["off"], np.int64), u=np.concatenate(rec["u"]).astype(np.float32),
+             ids=np.concatenate(rec["ids"]), lq=np.concatenate(rec["lq"]).astype(np.float64),
+             thr=np.concatenate(rec["thr"]).astype(np.float32), n_keep=np.concatenate(rec["n_keep"]),
+             ties_removed=np.concatenate(rec["ties_removed"]),
+             pick_margin=np.concatenate(rec["pick_margin"]).astype(np.float64), n_matches=np.array(rec["n_matches"], np.int32),
+             r=np.array(rec["r"], np.float32).reshape(-1, 3), tok=np.array(rec["tok"], np.int32).reshape(-1, 3),
+             margin=np.array(rec["margin"], np.float64).reshape(-1, 3))
+
+
 def gen_dynamic_lambda():
     """DynamicCostOptimizer._optimize_lambda_parameter (src/serving/dynamic_cost_optimizer.py:425-487) called unbound
     on a stand-in `self` (the class constructor would start its background thread); the reference source runs
@@ -640,6 +768,7 @@ def main():
     gen_dynamic_lambda()
     gen_top_p_nucleus()
     gen_speculative_sampling()
+    gen_speculative_sampling_full()
     print("wrote", sorted(os.listdir(OUT)))
 
 

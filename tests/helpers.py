@@ -182,3 +182,29 @@ def spec_cases(g):
         u = g["u"][int(g["u_off"][i]):int(g["u_off"][i + 1])].astype(np.float32)
         yield dict(K=K, V=V, cand=cand, new=new, tok=ids, lp_d=lq.astype(np.float32), u=u, n_matches=int(g["n_matches"][i]),
                    r=g["r"][i].astype(np.float32), want_tok=g["tok"][i].astype(np.int32), margin=g["margin"][i])
+
+
+# ---- A5 + residual + proposal at V = 152064 on bf16 / f16 rows with T = 0.7, top-p 0.9
+# (tests/golden/speculative_sampling_full.npz: transformers' warpers + _speculative_sampling)
+def spec_full_cases(g):
+    """Yield, per fixture case, the RAW rows as stored (regenerated from (seed, case) exactly as
+    oracle/gen_golden.py::spec_full_rows drew them) with HF's results: drafted tokens, log q(token), nucleus thresholds in
+    raw score units, acceptance uniforms, n_matches, residual-draw tokens."""
+    seed, V = int(g["seed"]), int(g["V"])
+    dts = {"bf16": O.DT_BF16, "f16": O.DT_F16}
+    for i in range(g["case"].shape[0]):
+        K, storage = int(g["K"][i]), str(g["storage"][i])
+        rng = np.random.default_rng([seed, int(g["case"][i])])
+        cand = (rng.standard_normal((K, V)) * float(g["scale"][i])).astype(np.float32)
+        new = np.empty((K + 1, V), np.float32)
+        new[:K] = (cand.astype(np.float64) + rng.standard_normal((K, V)) * float(g["spread"][i])).astype(np.float32)
+        new[K] = (rng.standard_normal(V) * float(g["scale"][i])).astype(np.float32)
+        pick = rng.uniform(0, 1, K).astype(np.float32)
+        a, b = int(g["off"][i]), int(g["off"][i + 1])
+        dt = dts[storage]
+        yield dict(case=int(g["case"][i]), K=K, V=V, dtype=dt, cand=encode_logits(cand, dt), new=encode_logits(new, dt), pick=pick,
+                   tok=g["ids"][a:b].astype(np.int32), lq=g["lq"][a:b], thr=g["thr"][a:b].astype(np.float32),
+                   n_keep=g["n_keep"][a:b], ties_removed=g["ties_removed"][a:b], pick_margin=g["pick_margin"][a:b],
+                   u=g["u"][a:b].astype(np.float32),
+                   n_matches=int(g["n_matches"][i]), r=g["r"][i].astype(np.float32), want_tok=g["tok"][i].astype(np.int32),
+                   margin=g["margin"][i], inv_t=float(np.float32(1.0) / np.float32(g["T"])), top_p=float(g["top_p"]))

@@ -240,3 +240,37 @@ def test_accept_rule_and_residual_distribution_against_hf_speculative_sampling(g
                 n_draws += 1
         n_cases += 1
     assert n_cases == 24 and n_draws >= 60
+
+
+def test_accept_residual_and_proposal_at_the_full_vocabulary_against_hf(golden):
+    """The same pin at the size and settings the path RUNS at: V = 152064, rows stored as bf16 / f16,
+    the reference's T = 0.7 / top_p = 0.9 (generate_training_data.py:110-119) -- the draft scores warped by HF's
+    TemperatureLogitsWarper + TopPLogitsWarper, `_speculative_sampling` called unmodified
+    (oracle/gen_golden.py::gen_speculative_sampling_full).  Oracle: n_acc == HF's n_matches on all 16 cases; the residual
+    draw against the NUCLEUS-TRUNCATED draft row (x* thresholds) picks HF's token wherever the draw is >= 1e-5 of the mass
+    from a CDF edge; the proposal step reproduces HF's nucleus threshold, drafted token and log q(token)."""
+    from helpers import spec_full_cases
+    g = golden.npz("speculative_sampling_full.npz")
+    n_cases = n_draws = n_prop = 0
+    for c in spec_full_cases(g):
+        K, V, dt = c["K"], c["V"], c["dtype"]
+        ref = O.verify_accept(c["new"][:K], dt, c["tok"], c["lq"].astype(np.float32), c["u"], 1, K, V, inv_temperature=c["inv_t"])
+        assert int(ref["n_acc"][0]) == c["n_matches"], c["case"]
+        # HF's warper drops some of the scores EQUAL to the nucleus threshold (its sort order decides), the kernels keep every
+        # tie: where that happened on the row the residual is taken against, q -- and with it p' -- differs by ~1e-3 of mass
+        same_residual = c["n_matches"] == K or c["ties_removed"][c["n_matches"]] == 0
+        for r, want, margin in zip(c["r"], c["want_tok"], c["margin"]):
+            tok, _ = O.residual_sample(c["new"][:K], c["cand"], dt, [c["n_matches"]], [r], 1, K, V, bonus=c["new"][K:K + 1],
+                                       inv_temperature=c["inv_t"], d_threshold=c["thr"].reshape(1, K))
+            if margin > 1e-5 and same_residual:
+                assert int(tok[0]) == int(want), c["case"]
+                n_draws += 1
+        d = O.draft_sample(c["cand"], dt, c["pick"], K, V, c["inv_t"], c["top_p"])
+        ok = d["margin_p"] > 1e-5
+        assert np.array_equal(d["thr"][ok], c["thr"][ok]), c["case"]
+        okt = ok & (c["pick_margin"] > 1e-5) & (d["margin_r"] > 1e-5) & (c["ties_removed"] == 0)   # same nucleus as HF's
+        assert np.array_equal(d["tok"][okt], c["tok"][okt]), c["case"]
+        np.testing.assert_allclose(d["lp"][okt], c["lq"][okt], rtol=0, atol=2e-5)
+        n_prop += int(okt.sum())
+        n_cases += 1
+    assert n_cases == 16 and n_draws >= 24 and n_prop >= 24
