@@ -32,15 +32,32 @@ def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 class HipOps:
-    """The product: device tensors through libasd_hip.so."""
+    """The product: device tensors through libasd_hip.so.
+
+    Re-entrant: the reference serves requests from a pool of up to 100 threads (src/serving/pipeline.py:83,155), so the
+    scratch a call needs -- verify workspaces, sampler mailboxes, lm_head partial buffers -- is kept PER CALLING THREAD
+    (a workspace must never be shared by calls that may overlap; each thread launches on its own current stream).  Only
+    the packed lm_head images are shared between threads: they are read-only snapshots of a weight matrix."""
 
     def __init__(self, pack_lm_head: bool = True):
         """pack_lm_head: lm_head matrices handed to lm_head_verify / lm_head_partial are re-laid out once, tile-major
-        (asd_lm_head_pack_weights: +V*D*2 bytes per matrix, 3-12 % faster streaming, bit-identical results)."""
+        (asd_lm_head_pack_weights: 3-12 % faster streaming, bit-identical results).  COST: one more copy of every such
+        matrix in HBM (+V*D*2 bytes: +2.5 GB for the 152064 x 8192 head of the 72B tier, +1.1 GB for the 7B one); pass
+        False where that memory is needed for KV or batch."""
+        import threading
         from . import kernels
         self.K = kernels
-        self._ws = {}
+        self._tls = threading.local()
+        self._packed = {}                    # weight key -> packed image (shared, read-only)
+        self._lock = threading.Lock()
         self.pack_lm_head = bool(pack_lm_head)
+
+    @property
+    def _ws(self):
+        d = getattr(self._tls, "ws", None)
+        if d is None:
+            d = self._tls.ws = {}
+        return d
 
     def _workspace(self, B, K, V, dtype, device):
         key = (B, K, str(dtype), str(device))
@@ -79,19 +96,32 @@ class HipOps:
         r = self.K.accept_from_partials(msg_all, lp_d, u, inv_temperature=inv_temperature)
         return r.lp_target, r.accept, r.n_acc, r.accept_bits
 
+    @staticmethod
+    def _weight_key(w):
+        """Identity of a weight matrix AS DATA: address, geometry, dtype and torch's in-place version counter.  The address
+        alone is not enough: an in-place update (`w.add_`, a checkpoint reload into the same storage) keeps it,
+        and a row slice of a larger matrix shares it."""
+        return (w.data_ptr(), tuple(w.shape), tuple(w.stride()), str(w.dtype), str(w.device), int(w._version))
+
     def _lm_head(self, weight, B, K):
-        key = ("lmh", weight.data_ptr(), B, K)
+        wkey = self._weight_key(weight)
+        key = ("lmh", wkey[0], K)
         ver = self._ws.get(key)
+        if ver is not None and (ver.wkey != wkey or ver.B < B):
+            ver = None                           # the matrix changed in place (repack), or a larger batch than it was sized for
         if ver is None:
-            packed = None
-            if self.pack_lm_head and weight.shape[1] % 64 == 0:
-                for k2, v2 in self._ws.items():          # one packed image per matrix, shared by every (B, K)
-                    if isinstance(k2, tuple) and k2[:2] == ("lmh", weight.data_ptr()) and v2.packed is not None:
-                        packed = v2.packed
-                        break
-            ver = self.K.LmHeadVerifier(weight, B, K, packed=self.pack_lm_head and packed is None and weight.shape[1] % 64 == 0)
-            if packed is not None:
-                ver.packed, ver._w_ptr, ver._ld_w = packed, packed.data_ptr(), 0
+            image = None
+            can_pack = self.pack_lm_head and weight.shape[1] % 64 == 0
+            if can_pack:
+                with self._lock:
+                    for k2 in [k2 for k2 in self._packed if k2[0] == wkey[0] and k2 != wkey]:
+                        del self._packed[k2]     # stale snapshots of this storage
+                    image = self._packed.get(wkey)
+            ver = self.K.LmHeadVerifier(weight, B, K, packed=can_pack and image is None, packed_image=image)
+            ver.wkey = wkey
+            if can_pack and image is None:
+                with self._lock:
+                    self._packed.setdefault(wkey, ver.packed)
             self._ws[key] = ver
         return ver
 

@@ -185,9 +185,12 @@ class LmHeadVerifier:
     workspace for one (B, K, V); `weight` is the [V, D] bf16 or f16 lm_head matrix (nn.Linear layout); the hidden
     states must have the same element type."""
 
-    def __init__(self, weight: torch.Tensor, B_: int, K: int, packed: bool = False):
-        """packed=True: keep a tile-major copy of the matrix (asd_lm_head_pack_weights; +V*D*2 bytes) and stream that:
-        every 64-deep reduction step of a column block is one contiguous 32 KiB run.  Results are bit-identical."""
+    def __init__(self, weight: torch.Tensor, B_: int, K: int, packed: bool = False, packed_image: Optional[torch.Tensor] = None):
+        """Sized for batches of up to B_ sequences of exactly K positions (calls with fewer sequences reuse the workspace).
+        packed=True: keep a tile-major copy of the matrix (asd_lm_head_pack_weights; +V*D*2 bytes, e.g. +2.5 GB for the
+        152064 x 8192 head) and stream that: every 64-deep reduction step of a column block is one contiguous 32 KiB run.
+        packed_image: an image another verifier of the SAME matrix already built (shared, read-only).
+        Results are bit-identical either way.  The image is a snapshot: repack after changing the weights."""
         if weight.dim() != 2 or weight.dtype not in (torch.bfloat16, torch.float16) or not weight.is_cuda:
             raise ValueError("weight must be a [V, D] bf16 or f16 CUDA tensor")
         self._dt = _DTYPE_CODE[weight.dtype]
@@ -198,7 +201,10 @@ class LmHeadVerifier:
         self.V, self.D = weight.shape
         self._w_ptr, self._ld_w = weight.data_ptr(), weight.stride(0)
         self.packed = None
-        if packed:
+        if packed_image is not None:
+            self.packed = packed_image
+            self._w_ptr, self._ld_w = packed_image.data_ptr(), 0
+        elif packed:
             nbytes = int(_lib().asd_lm_head_packed_bytes(self.V, self.D))
             if nbytes == 0:
                 raise ValueError("D must be a multiple of 64 to pack the lm_head")
@@ -216,8 +222,8 @@ class LmHeadVerifier:
         greedy=True: accept[b,k] = (tok[b,k] == argmax logits[b,k]) (lp_draft / u unused);
         argmax_out: optional [B, K] int32 tensor that receives the row arg-max either way."""
         Bv, K = tok.shape
-        if (Bv, K) != (self.B, self.K):
-            raise ValueError(f"verifier was sized for B={self.B}, K={self.K}, got {Bv}, {K}")
+        if Bv > self.B or K != self.K:
+            raise ValueError(f"verifier was sized for B<={self.B}, K={self.K}, got {Bv}, {K}")
         if not greedy and (lp_draft is None or u is None):
             raise ValueError("lp_draft and u are required unless greedy=True")
         h2 = hidden.reshape(Bv * K, hidden.shape[-1]) if hidden.dim() == 3 else hidden
@@ -245,8 +251,8 @@ class LmHeadVerifier:
         """`self.weight` is this rank's vocabulary shard starting at global id `v_offset`: returns the
         [B, K, 3] (m2, s, g) message of asd_lse_partial without forming the shard's logits (asd_lm_head_partial)."""
         Bv, K = tok.shape
-        if (Bv, K) != (self.B, self.K):
-            raise ValueError(f"verifier was sized for B={self.B}, K={self.K}, got {Bv}, {K}")
+        if Bv > self.B or K != self.K:
+            raise ValueError(f"verifier was sized for B<={self.B}, K={self.K}, got {Bv}, {K}")
         h2 = hidden.reshape(Bv * K, hidden.shape[-1]) if hidden.dim() == 3 else hidden
         if h2.dtype != self.weight.dtype or h2.shape != (Bv * K, self.D) or h2.stride(1) != 1:
             raise ValueError("hidden must be [B*K, D] of the weight's element type with contiguous rows")
