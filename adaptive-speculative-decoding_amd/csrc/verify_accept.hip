@@ -71,8 +71,9 @@ namespace asd {
 namespace {
 
 constexpr int kMaxStage = 1024;        // granules one finisher stages in LDS (K*S <= kMaxStage)
-constexpr int kTicketStride = 128;     // u32 units: 512 bytes per sequence = ticket/ballot line + two lines of K lp_t slots (+ one spare)
-constexpr int kLpLineOffset = 32;      // u32 units: where the fused epilogue's lp_t hand-off slots start (kFastMaxK x 8 bytes)
+constexpr int kTicketStride = 160;     // u32 units: 640 bytes per sequence = ballot line + four lines of up to 64 hand-off slots (8 bytes each)
+constexpr int kLpLineOffset = 32;      // u32 units: where the slots start -- (lp_t, flag) per row with one workgroup per row + in-kernel
+                                       // epilogue; the drafted token's logit per row with split rows
 constexpr int kSpinLimit = 1 << 20;    // polls of a slot whose store is in flight before its row is poisoned
 constexpr int kFastMaxK = 32;          // ballot-by-atomic packs K flags + a 32-bit count in one u64
 
@@ -213,7 +214,10 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     // traffic of the loop and stall wave 0 at its first tile claim
     int vrow = row;
     asm volatile("" : "+v"(vrow));
-    if (own_row && tid == 0) raw_tok = static_cast<uint32_t>(a_tok[vrow]);   // the oldest load of wave 0: waited for alone
+    // split rows: slice 0 of a row fetches the drafted token's logit under its stream and hands it to the finisher (round 2: the
+    // finisher loaded tok, then the logit -- two dependent round trips on the tail of every sequence)
+    const bool gather = own_row || split == 0;
+    if (gather && tid == 0) raw_tok = static_cast<uint32_t>(a_tok[vrow]);   // the oldest load of wave 0: waited for alone
 
     // ---- streaming: waves claim UNROLL-KiB tiles from an LDS counter ---------------------------
     // Static striding lets the oldest wave group run ahead (age-priority arbitration: measured
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     // logit) and the <= 7-element unaligned head / ragged tail of the row -- issued, not waited for
     asm volatile("" : "+v"(raw_tok));   // first use of the token id: here, not hoisted in front of the tile loads
     const int64_t t_tok = static_cast<int64_t>(static_cast<int32_t>(raw_tok)) - p.v_offset;
-    if (own_row && tid == 0 && t_tok >= 0 && t_tok < a_V) {
+    if (gather && tid == 0 && t_tok >= 0 && t_tok < a_V) {
         raw_x = E::raw(rowp, t_tok);
         have_x = true;
     }
@@ -343,9 +347,9 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             stage[n_tiles] = (static_cast<uint64_t>(__float_as_uint(hs)) << 32) | __float_as_uint(hm);
             if (STATS) stage_t[n_tiles] = ht;
         }
-        if (own_row && tid == 0) {
+        if (gather && tid == 0) {
             if (have_x) x_tok = E::from_raw(raw_x);
-            if (p.mode == 0) {
+            if (own_row && p.mode == 0) {
                 lpd = __uint_as_float(raw_lpd);
                 uu = __uint_as_float(raw_u);
                 lu_row = log_u(uu);
@@ -456,37 +460,36 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         return;
     }
 
-    // ---- split rows: publish the slice, take a ticket ------------------------------------------
+    // ---- split rows: publish the slice; the sequence's designated finisher collects -----------------------------
+    // No ticket (round 3): the finisher is the LAST workgroup of the sequence in dispatch order -- last row, last slice -- and
+    // simply polls every slot of its sequence (self-tagging, bounded, poisoning; each slot has this one reader).  Round 2
+    // took a ticket per slice and let the last arriver load tok and then the token's logit: three dependent memory round
+    // trips (ticket, tok, logit) behind the last slice of every sequence, ~3 us of an 8 us launch at B = 8.
     const int KS = p.K * S;
     uint64_t* region = p.granules + static_cast<int64_t>(b) * p.region;
-    uint32_t* ticket = p.tickets + static_cast<int64_t>(b) * kTicketStride;
-    int last = 0;
-    if (lane == 0) {
-        // a granule is never all-zero bits (s > 0, or m2 is the sentinel), an EMPTY slot is: the granule tags itself.
-        // So the store is not drained before the ticket (that was one store-ack round trip on every slice's tail):
-        // the finisher re-reads a slot until it is non-zero -- every store it waits for was ISSUED before the ticket
-        // add whose return value made it the finisher, so the wait is bounded by one store latency -- and hands the
-        // slot back empty.
+    uint64_t* xslots = reinterpret_cast<uint64_t*>(p.tickets + static_cast<int64_t>(b) * kTicketStride + kLpLineOffset);
+    if (lane == 0 && row * S + split + 1 != p.withhold1) {
+        // a granule is never all-zero bits (s > 0, or m2 is the sentinel), an EMPTY slot is: the granule tags itself
         const uint64_t g = (static_cast<uint64_t>(__float_as_uint(s)) << 32) | __float_as_uint(m2);
-        if (row * S + split + 1 != p.withhold1)
-            __hip_atomic_store(region + k * S + split, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = (old == static_cast<uint32_t>(KS - 1));
+        __hip_atomic_store(region + k * S + split, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (split == 0)   // x_tok may be -inf (token outside the shard) or NaN: the tag bit keeps the slot non-zero
+            __hip_atomic_store(xslots + k, (1ull << 63) | __float_as_uint(x_tok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    last = __shfl(last, 0, 64);
-    if (!last) return;
+    if (k != p.K - 1 || split != S - 1) return;
 
-    // ---- last arriver of sequence b: finish its K rows ------------------------------------
+    // ---- designated finisher of sequence b: finish its K rows ------------------------------------
     EpiLate late;
     if (FUSED) {
-        if (fused) epi_late_prefetch(p.epi, b, lane, late);   // under the token / logit gathers and the granule polls below
+        if (fused) epi_late_prefetch(p.epi, b, lane, late);   // under the polls below
     }
     const int frow = b * p.K + lane;  // lane <-> draft position
+    bool lost_x = false;
     if (lane < p.K) {
-        const int64_t t = static_cast<int64_t>(p.tok[frow]) - p.v_offset;
-        if (t >= 0 && t < p.V)
-            x_tok = E::scalar(static_cast<const char*>(p.logits) + static_cast<int64_t>(frow) * p.ld_row * E::kBytes, t);
         if (p.mode == 0) { lpd = p.lp_d[frow]; uu = p.u[frow]; }
+        const uint64_t xv = poll_slot(xslots + lane);
+        __hip_atomic_store(xslots + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lost_x = xv == 0ull;
+        x_tok = __uint_as_float(static_cast<uint32_t>(xv));
     }
     for (int g = lane; g < KS; g += 64) {
         stage[g] = poll_slot(region + g);       // 0 = lost: poisons its row below
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     float fm = kSentinel, fs = 0.0f;
-    bool lost = false;
+    bool lost = lost_x;
     if (lane < p.K) {
         for (int j = 0; j < S; ++j) {
             const uint64_t g = stage[lane * S + j];
@@ -506,7 +509,6 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         }
         if (lost) { fm = NAN; fs = NAN; }       // a slice never arrived: lp_t = NaN, the row is rejected
     }
-    if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     if (p.mode == 1) {
         if (lane < p.K) {

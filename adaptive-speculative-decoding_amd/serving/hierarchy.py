@@ -110,6 +110,19 @@ class FinalMsg:
     tier: torch.Tensor     # [B] i32  the tier whose verdict was committed
 
 
+def _timed(role, fn):
+    """Run a model pass; with role.events a list, bracket it with HIP events on the current stream (bench.py: the per-tier
+    torch time beside the hot-path calls)."""
+    if role.events is None or not torch.cuda.is_available():
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    role.events.append((e0, e1))
+    return out
+
+
 def _dev_gen(device, seed: int) -> torch.Generator:
     return torch.Generator(device=device).manual_seed(int(seed))
 
@@ -164,6 +177,8 @@ class DraftRole:
         if self.st.P > 2:
             model.forward_ragged(prompt_ids[:, :self.st.P - 2], torch.zeros((B,), dtype=torch.int64, device=dev), self.st.P)
         self.rows_b = torch.arange(B, device=dev)
+        self.fwd_calls = self.fwd_positions = 0            # model passes / sequence-positions computed (loop roofline)
+        self.events: Optional[list] = None                 # set to [] to bracket the model passes with HIP events
         self.d_logits: Optional[torch.Tensor] = None       # [B,K,V] of the current block (storage dtype)
         self.thr = torch.empty((B, K), dtype=torch.float32, device=dev)
         self.tok = torch.empty((B, K), dtype=torch.int32, device=dev)
@@ -176,7 +191,9 @@ class DraftRole:
         L = st.seq_len.to(torch.int64)
         w = st.window()
         last2 = torch.stack([st.tokens[self.rows_b, L - 2], st.tokens[self.rows_b, L - 1]], 1).to(torch.int64)
-        dl = self.m.forward_ragged(last2, L - 2, w)[:, -1]
+        dl = _timed(self, lambda: self.m.forward_ragged(last2, L - 2, w))[:, -1]
+        self.fwd_calls += 1
+        self.fwd_positions += 2 * B
         if self.d_logits is None:
             self.d_logits = torch.empty((B, K, dl.shape[-1]), dtype=dl.dtype, device=dl.device)
         for k in range(K):
@@ -185,7 +202,9 @@ class DraftRole:
             t, lp, thr = self.ops.draft_sample(self.d_logits[:, k], r, self.inv_t, cfg.top_p)
             self.tok[:, k], self.lp_d[:, k], self.thr[:, k] = t, lp, thr
             if k + 1 < K:
-                dl = self.m.forward_ragged(t[:, None].to(torch.int64), L + k, w)[:, -1]
+                dl = _timed(self, lambda: self.m.forward_ragged(t[:, None].to(torch.int64), L + k, w))[:, -1]
+                self.fwd_calls += 1
+                self.fwd_positions += B
         # stage 0 of the stop rule: the draft tier judged from its own log-probs
         ph = torch.ones((B, self.L), dtype=torch.float64, device=dl.device)
         _, k0, ph = self.ops.predictor_stop(self.pred, self.lp_d, self.feat, ph, 0, self.costs, cfg.lambda_value,
@@ -322,6 +341,8 @@ class VerifyRole:
         self._fed: Optional[torch.Tensor] = None            # sequences fed this step (their KV advanced)
         self._pending = None
         self.fed_tokens = 0                                 # model positions computed (cost accounting)
+        self.fwd_calls = 0                                  # model passes (loop roofline: each streams the tier's weights once)
+        self.events: Optional[list] = None                  # set to [] to bracket the model passes with HIP events
 
     def _empty(self) -> Verdict:
         z = torch.zeros_like(self.st.seq_len)
@@ -355,8 +376,9 @@ class VerifyRole:
         tok_i = dm.tok[idx]
         drafted = tok_i.gather(1, (pos - L[:, None]).clamp(0, K - 1)).to(torch.int64)
         ids = torch.where(pos < L[:, None], committed, torch.where(pos < (L + K)[:, None], drafted, torch.zeros_like(drafted)))
-        hid = self.m.forward_ragged(ids, kv, st.window(), return_hidden=True, rows=None if n == B else idx)
+        hid = _timed(self, lambda: self.m.forward_ragged(ids, kv, st.window(), return_hidden=True, rows=None if n == B else idx))
         self.fed_tokens += n * T
+        self.fwd_calls += 1
         sel = lag[:, None] + torch.arange(K + 1, device=dev)
         hid = hid.gather(1, sel[:, :, None].expand(-1, -1, hid.shape[-1]))              # [n, K+1, D]
         u = torch.rand((B, K), generator=self.gen, device=dev)[idx].contiguous()
@@ -473,6 +495,38 @@ def calibrate_lambda(ops, p_hist: torch.Tensor, costs: torch.Tensor, stage_idx: 
     return best_lam, best_share
 
 
+class StopRateController:
+    """calibrate_lambda as a RUNNING controller (the token-level counterpart of DynamicLambdaController /
+    src/serving/dynamic_cost_optimizer.py:425-487, which nudges lambda from rolling statistics): it keeps the p_hist rows
+    of the blocks tier `stage_idx` judged during the last `window` steps and, every `every` steps, re-solves -- ONE
+    asd_lambda_sweep launch per refinement round over that window -- for the lambda whose stop share at that tier is
+    `target_stop_rate`; the roles' shared HierarchyConfig.lambda_value is updated in place.  A one-shot calibration on a
+    probe step drifts as soon as the population of blocks moves (round 2: target 0.66, live 0.48)."""
+
+    def __init__(self, ops, cfg: HierarchyConfig, costs: torch.Tensor, stage_idx: int = 1, target_stop_rate: float = 0.66,
+                 window: int = 4, every: int = 1, lo: float = 0.05, hi: float = 500.0):
+        self.ops, self.cfg, self.costs, self.s = ops, cfg, costs, stage_idx
+        self.target, self.window, self.every = float(target_stop_rate), int(window), int(every)
+        self.lo, self.hi = lo, hi
+        self.rows: List[torch.Tensor] = []
+        self.steps = 0
+        self.history: List[Tuple[float, float]] = []        # (lambda, share of the window that stops at it)
+
+    def observe(self, p_hist: Optional[torch.Tensor]) -> None:
+        """p_hist [n, L] of the blocks the tier judged this step (columns above it at their prior)."""
+        if p_hist is not None and p_hist.shape[0]:
+            self.rows.append(p_hist.detach().clone())
+            del self.rows[:-self.window]
+
+    def end_step(self) -> float:
+        self.steps += 1
+        if self.rows and self.steps % self.every == 0:
+            lam, share = calibrate_lambda(self.ops, torch.cat(self.rows, 0), self.costs, self.s, self.target, self.lo, self.hi)
+            self.cfg.lambda_value = lam
+            self.history.append((lam, share))
+        return self.cfg.lambda_value
+
+
 # ------------------------------------------------------------------------------------------- drivers
 @dataclass
 class HierarchyTrace:
@@ -486,6 +540,9 @@ class HierarchyTrace:
     records: List[dict] = field(default_factory=list)        # per step (keep_inputs)
     bytes_sent: Dict[str, int] = field(default_factory=dict)
     rows_shipped: int = 0
+    tier_forwards: List[int] = field(default_factory=list)   # model forward passes per tier (tier 0: K per step)
+    tier_forward_positions: List[int] = field(default_factory=list)   # sequence-positions those passes computed
+    lambda_history: List[float] = field(default_factory=list)         # lambda in force at every step (StopRateController)
 
     @property
     def stop_rate(self) -> List[float]:
@@ -503,8 +560,9 @@ def _account(tr: HierarchyTrace, L: int, final: FinalMsg, verdicts) -> None:
 
 @torch.no_grad()
 def generate_hierarchical(draft: DraftRole, tiers: Sequence[VerifyRole], max_steps: Optional[int] = None,
-                          keep_inputs: bool = False) -> HierarchyTrace:
-    """All roles in ONE process (one GPU holds every tier): the reference configuration of the multi-rank run."""
+                          keep_inputs: bool = False, controller: Optional["StopRateController"] = None) -> HierarchyTrace:
+    """All roles in ONE process (one GPU holds every tier): the reference configuration of the multi-rank run.
+    controller: a StopRateController over the roles' shared config -- lambda then follows the running stop share."""
     L = draft.L
     assert len(tiers) == L - 1
     tr = HierarchyTrace(draft.st.tokens, draft.st.seq_len, tier_counts=[0] * L, tier_calls=[0] * L)
@@ -516,6 +574,8 @@ def generate_hierarchical(draft: DraftRole, tiers: Sequence[VerifyRole], max_ste
         rec = dict(draft=dm, tiers={})
         for t in tiers:
             v, esc_out = t.verify(dm, esc)
+            if controller is not None and t.s == controller.s:
+                controller.observe(v.p_hist)
             if int(v.active.sum().item()) > 0:
                 b_rows, d_rows, d_thr = draft.rows_for(v)
                 tr.rows_shipped += int(b_rows.numel())
@@ -536,9 +596,14 @@ def generate_hierarchical(draft: DraftRole, tiers: Sequence[VerifyRole], max_ste
         if keep_inputs:
             tr.records.append(rec)
         tr.steps += 1
+        tr.lambda_history.append(float(draft.cfg.lambda_value))
+        if controller is not None:
+            controller.end_step()
         if int(draft.st.seq_len.min().item()) >= cap:
             break
     tr.fed_tokens = [t.fed_tokens for t in tiers]
+    tr.tier_forwards = [draft.fwd_calls] + [t.fwd_calls for t in tiers]
+    tr.tier_forward_positions = [draft.fwd_positions] + [t.fed_tokens for t in tiers]
     return tr
 
 
@@ -641,7 +706,7 @@ class Wire:
 def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[DraftRole], tiers: Dict[int, VerifyRole],
                           B: int, K: int, L: int, V: int, logits_dtype: torch.dtype, cap: int, device,
                           max_steps: Optional[int] = None, group=None, keep_inputs: bool = False,
-                          loopback: bool = False) -> HierarchyTrace:
+                          loopback: bool = False, controller: Optional["StopRateController"] = None) -> HierarchyTrace:
     """One rank of the multi-rank loop.  `draft` is the DraftRole if this rank hosts tier 0, `tiers` maps stage index
     -> VerifyRole for the verify tiers this rank hosts (leader or vocab shard).  Every rank executes the same step
     sequence; only the messages listed in the module docstring cross ranks.  The committed stream is identical to
@@ -691,6 +756,10 @@ def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[Draft
             if rank in ranks_s:
                 v, esc_out = tiers[s].verify(dm, esc_in)
                 runs_t = bool(v.active.any().item())
+                # the controller lives where its tier does: lambda only enters that tier's stop-or-escalate decision
+                # (tier 0 never stops a block with min_verify_stage = 1, the last tier always does), so nothing is broadcast
+                if controller is not None and s == controller.s and rank == lead:
+                    controller.observe(v.p_hist)
                 if runs_t and rank == lead:
                     wire.send("verdict", [v.active, v.stop, v.n_acc], lead, [D])
             if rank == D and runs_d:
@@ -730,9 +799,14 @@ def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[Draft
         if keep_inputs:
             tr.records.append(rec)
         tr.steps += 1
+        if controller is not None and controller.s in tiers and rank == placement.leader(controller.s):
+            tr.lambda_history.append(float(tiers[controller.s].cfg.lambda_value))
+            controller.end_step()
         if int(state.seq_len.min().item()) >= cap:
             break
     tr.fed_tokens = [tiers[s].fed_tokens if s in tiers else 0 for s in range(1, L)]
+    tr.tier_forwards = [draft.fwd_calls if draft is not None else 0] + [tiers[s].fwd_calls if s in tiers else 0 for s in range(1, L)]
+    tr.tier_forward_positions = [draft.fwd_positions if draft is not None else 0] + tr.fed_tokens
     tr.bytes_sent = dict(wire.bytes)
     return tr
 

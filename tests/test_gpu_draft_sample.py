@@ -348,7 +348,7 @@ def test_group_kernel_masked_tied_and_dominant_rows(K_):
             tok, lp, thr = _run_with_groups(K_, g, store, r, B, V, dtype, 1.0, 0.9)
             okp = ref["margin_p"] > 1e-5
             ok = okp & (ref["margin_r"] > 1e-5)
-            assert ok[[0, 1, 3]].all()
+            assert ok[[1, 3]].all()          # (row 0: 65536 equal masses, top_p is never 1e-5 from a step; checked below)
             assert np.array_equal(thr[okp], ref["thr"][okp])
             assert np.array_equal(tok[ok], ref["tok"][ok])
             np.testing.assert_allclose(lp[ok], ref["lp"][ok], atol=LP_ATOL, rtol=1e-6)
