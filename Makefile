@@ -19,7 +19,14 @@ bench:
 golden:           ## regenerate tests/golden from the reference's own files (dev container only)
 	PYTHONDONTWRITEBYTECODE=1 $(PY) oracle/gen_golden.py
 
+asan-host:        ## host side of the launchers under AddressSanitizer + UBSan (CPU only: the ABI / argument-check tests)
+	$(PY) adaptive-speculative-decoding_amd/build.py --asan
+	ASD_LIB_PATH=$(CURDIR)/adaptive-speculative-decoding_amd/lib/libasd_hip_asan.so \
+	LD_PRELOAD=$$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so) \
+	ASAN_OPTIONS=detect_leaks=0:detect_odr_violation=0:verify_asan_link_order=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+	$(PY) -m pytest tests/test_abi.py -q -p no:cacheprovider
+
 clean:
 	rm -rf adaptive-speculative-decoding_amd/lib oracle/_build gpurun_out
 
-.PHONY: build test-cpu test-gpu smoke bench golden clean
+.PHONY: build test-cpu test-gpu smoke bench golden asan-host clean

@@ -12,7 +12,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libasd_hip.so")
+# ASD_LIB_PATH: load another build of the SAME library (the host-sanitizer build of `make asan-host`); never a fallback
+LIB_PATH = os.environ.get("ASD_LIB_PATH") or os.path.join(_HERE, "lib", "libasd_hip.so")
 
 ASD_OK = 0
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2

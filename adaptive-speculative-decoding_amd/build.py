@@ -50,8 +50,21 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+ASAN_LIB = os.path.join(LIBDIR, "libasd_hip_asan.so")
+ASAN_FLAGS = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-g"]
+
+
+def build(force: bool = False, verbose: bool = False, asan: bool = False) -> str:
+    """asan=True: a SECOND library, lib/libasd_hip_asan.so, whose HOST code (argument checks, geometry heuristics, workspace
+    layout, launch plumbing) is compiled with AddressSanitizer + UBSan (`-Xarch_host`: the device code is untouched -- GPU
+    sanitizers are not available on this pool).  `make asan-host` runs the CPU-side ABI tests against it."""
     hipcc = _hipcc()
+    global OBJDIR, LIB
+    objdir, lib = (os.path.join(LIBDIR, "obj_asan"), ASAN_LIB) if asan else (OBJDIR, LIB)
+    return _build(hipcc, objdir, lib, ASAN_FLAGS if asan else [], force, verbose)
+
+
+def _build(hipcc, OBJDIR, LIB, more, force, verbose) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers += [os.path.join(INC, "asd_hip.h"), os.path.abspath(__file__)]
@@ -61,7 +74,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+            jobs.append([hipcc, *COMMON, *extra, *more, "-c", s, "-o", o])
     if jobs:                                   # one hipcc per translation unit, side by side (each is single-threaded)
         from concurrent.futures import ThreadPoolExecutor
 
@@ -72,7 +85,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as pool:
             list(pool.map(run, jobs))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *([a for a in more if a not in ("-Xarch_host", "-g")]), "-o", LIB, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -80,4 +93,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, asan="--asan" in sys.argv))

@@ -647,29 +647,41 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_group(const DgParams p) {
             if (!leader) {
                 unsigned long long* out = hist_mine + lv * kDsDigits;     // a round has its own area: no word is reused inside a call
                 for (int i = t; i < bins; i += kDrThreads) dg_put(out + i, u.hist[i] | kDgValid);
-                if (t == 0) {
-                    w0 = dg_poll(mail + 2 * (1 + lv), &lost);
-                    w1 = dg_poll(mail + 2 * (1 + lv) + 1, &lost);
-                    dg_put(mail + 2 * (1 + lv), 0ull);
-                    dg_put(mail + 2 * (1 + lv) + 1, 0ull);
-                    bc[0] = w0;
-                    bc[1] = w1;
+                if (t < 2) {                               // the decision's two words, polled side by side
+                    bc[t] = dg_poll(mail + 2 * (1 + lv) + t, &lost);
+                    dg_put(mail + 2 * (1 + lv) + t, 0ull);
                 }
                 __syncthreads();
                 if (lost) return;
                 w0 = bc[0];
                 w1 = bc[1];
             } else {
-                // gather: bin i of every partner (one reader per word: this thread), summed with the leader's own
-                for (int i = t; i < bins; i += kDrThreads) {
-                    unsigned long long sum = u.hist[i];
-                    for (int pg = 1; pg < G; ++pg) {
-                        unsigned long long* in = p.hist_x + ((static_cast<int64_t>(b) * G + pg) * kDgMaxLevels + lv) * kDsDigits + i;
-                        const unsigned long long v = dg_poll(in, &lost);
-                        dg_put(in, 0ull);
-                        sum += v & ~kDgValid;
+                // gather: every (partner, bin) word has ONE reader -- thread (item mod 1024) -- and all of a thread's loads are in
+                // flight together: the words are added into the leader's own histogram with LDS atomics (integer adds commute).
+                // (First version: one thread per bin polling its G - 1 partners one after the other = G - 1 DEPENDENT memory
+                // round trips, 7 us at G = 8 and 25 us at G = 32.)
+                const int items = (G - 1) * bins;
+                for (int it0 = t; it0 < items; it0 += 4 * kDrThreads) {
+                    unsigned long long* in[4];
+                    unsigned long long v[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int it = it0 + q4 * kDrThreads;
+                        const int pg = 1 + it / bins, bin = it - (pg - 1) * bins;
+                        in[q4] = p.hist_x + ((static_cast<int64_t>(b) * G + pg) * kDgMaxLevels + lv) * kDsDigits + bin;
+                        v[q4] = it < items ? __hip_atomic_load(in[q4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kDgValid;
                     }
-                    u.hist[i] = sum;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int it = it0 + q4 * kDrThreads;
+                        if (it < items) {
+                            if (v[q4] == 0ull) v[q4] = dg_poll(in[q4], &lost);      // still in flight: wait for this one
+                            dg_put(in[q4], 0ull);
+                            const int pg = 1 + it / bins;
+                            const unsigned long long add = v[q4] & ~kDgValid;
+                            if (add) atomicAdd(&u.hist[it - (pg - 1) * bins], add);
+                        }
+                    }
                 }
                 __syncthreads();
                 // scan from the top: thread t owns the t-th chunk of bins counted from the TOP

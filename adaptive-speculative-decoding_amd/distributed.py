@@ -25,6 +25,8 @@ from typing import Tuple
 import torch
 import torch.distributed as dist
 
+from .trace import traced
+
 
 def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous, balanced [start, end) of `total` items for `rank` of `world`."""
@@ -39,8 +41,11 @@ class HipOps:
     (a workspace must never be shared by calls that may overlap; each thread launches on its own current stream).  Only
     the packed lm_head images are shared between threads: they are read-only snapshots of a weight matrix."""
 
-    def __init__(self, pack_lm_head: bool = True):
-        """pack_lm_head: lm_head matrices handed to lm_head_verify / lm_head_partial are re-laid out once, tile-major
+    def __init__(self, pack_lm_head: bool = True, profile: bool = False):
+        """profile: bracket every verify step (verify_accept / verify_stop / lm_head_verify) with a HIP event pair on the
+        calling thread's stream; `stats()` then reports `kernel_us` / `hbm_gbps` of the last one (the keys SURVEY §5 adds
+        to the reference's get_stats(), pipeline.py:346-370).  Off by default: an event pair costs 5-15 us on this stack.
+        pack_lm_head: lm_head matrices handed to lm_head_verify / lm_head_partial are re-laid out once, tile-major
         (asd_lm_head_pack_weights: 3-12 % faster streaming, bit-identical results).  COST: one more copy of every such
         matrix in HBM (+V*D*2 bytes: +2.5 GB for the 152064 x 8192 head of the 72B tier, +1.1 GB for the 7B one); pass
         False where that memory is needed for KV or batch."""
@@ -51,6 +56,28 @@ class HipOps:
         self._packed = {}                    # weight key -> packed image (shared, read-only)
         self._lock = threading.Lock()
         self.pack_lm_head = bool(pack_lm_head)
+        self.profile = bool(profile)
+        self._last = None                    # (event0, event1, algorithmic bytes, what)
+
+    def _timed_step(self, what, nbytes, fn):
+        if not self.profile:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self._last = (e0, e1, int(nbytes), what)
+        return out
+
+    def stats(self):
+        """{"kernel_us", "hbm_gbps", "step"} of the last profiled verify step (waits for it to finish); {} if none."""
+        if self._last is None:
+            return {}
+        e0, e1, nbytes, what = self._last
+        e1.synchronize()
+        us = 1e3 * e0.elapsed_time(e1)
+        return {"kernel_us": us, "hbm_gbps": nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0, "step": what,
+                "algorithmic_bytes": nbytes}
 
     @property
     def _ws(self):
@@ -66,12 +93,16 @@ class HipOps:
             ws = self._ws[key] = self.K.VerifyWorkspace(B, K, V, dtype, device)
         return ws
 
+    @traced("verify_accept")
     def verify_accept(self, logits, tok, lp_d, u, inv_temperature: float = 1.0):
         B, K = tok.shape
         ws = self._workspace(B, K, logits.shape[-1], logits.dtype, logits.device)
-        r = self.K.verify_accept(logits, tok, lp_d, u, ws, inv_temperature=inv_temperature)
+        nbytes = B * K * logits.shape[-1] * logits.element_size() + 17 * B * K + 12 * B
+        r = self._timed_step("asd_verify_accept", nbytes,
+                             lambda: self.K.verify_accept(logits, tok, lp_d, u, ws, inv_temperature=inv_temperature))
         return r.lp_target, r.accept, r.n_acc, r.accept_bits
 
+    @traced("verify_stop")
     def verify_stop(self, logits, tok, lp_d, u, inv_temperature, pred, feat, p_hist, stage_idx, costs, lam,
                     risk_adjustment=True, n_obs=100, alpha=1.0, beta=1.0, stats_col=5):
         """ONE launch per tier step (asd_verify_accept_fused_ex): verify + accept, then -- inside the same kernel, by the
@@ -81,17 +112,20 @@ class HipOps:
         B, K = tok.shape
         ws = self._workspace(B, K, logits.shape[-1], logits.dtype, logits.device)
         packed, in_dim, hidden = pred
-        v, r = self.K.verify_accept_fused(logits, tok, lp_d, u, ws, feat, packed, in_dim, hidden, stage_idx=stage_idx,
-                                          L=p_hist.shape[1], stats_col=stats_col, risk_adjustment=risk_adjustment, n_obs=n_obs,
-                                          alpha=alpha, beta=beta, p_hist=p_hist, Cc=costs, lam=lam,
-                                          inv_temperature=inv_temperature)
+        nbytes = B * K * logits.shape[-1] * logits.element_size() + 17 * B * K + 12 * B
+        v, r = self._timed_step("asd_verify_accept_fused_ex", nbytes, lambda: self.K.verify_accept_fused(
+            logits, tok, lp_d, u, ws, feat, packed, in_dim, hidden, stage_idx=stage_idx, L=p_hist.shape[1], stats_col=stats_col,
+            risk_adjustment=risk_adjustment, n_obs=n_obs, alpha=alpha, beta=beta, p_hist=p_hist, Cc=costs, lam=lam,
+            inv_temperature=inv_temperature))
         return (v.lp_target, v.accept, v.n_acc, v.accept_bits), (r.score, r.k_star, p_hist)
 
+    @traced("lse_partial")
     def lse_partial(self, logits_shard, tok, v_offset, inv_temperature: float = 1.0):
         B, K = tok.shape
         ws = self._workspace(B, K, logits_shard.shape[-1], logits_shard.dtype, logits_shard.device)
         return self.K.lse_partial(logits_shard, tok, v_offset, ws, inv_temperature=inv_temperature)
 
+    @traced("accept_from_partials")
     def accept_from_partials(self, msg_all, lp_d, u, inv_temperature: float = 1.0):
         r = self.K.accept_from_partials(msg_all, lp_d, u, inv_temperature=inv_temperature)
         return r.lp_target, r.accept, r.n_acc, r.accept_bits
@@ -114,8 +148,8 @@ class HipOps:
             can_pack = self.pack_lm_head and weight.shape[1] % 64 == 0
             if can_pack:
                 with self._lock:
-                    for k2 in [k2 for k2 in self._packed if k2[0] == wkey[0] and k2 != wkey]:
-                        del self._packed[k2]     # stale snapshots of this storage
+                    for k2 in [k2 for k2 in self._packed if k2[:5] == wkey[:5] and k2 != wkey]:
+                        del self._packed[k2]     # older versions of this very matrix (a row slice at the same address is its own entry)
                     image = self._packed.get(wkey)
             ver = self.K.LmHeadVerifier(weight, B, K, packed=can_pack and image is None, packed_image=image)
             ver.wkey = wkey
@@ -125,14 +159,18 @@ class HipOps:
             self._ws[key] = ver
         return ver
 
+    @traced("lm_head_partial")
     def lm_head_partial(self, hidden, weight_shard, tok, v_offset, inv_temperature: float = 1.0):
         B, K = tok.shape
         return self._lm_head(weight_shard, B, K).partial(hidden, tok, v_offset, inv_temperature)
 
+    @traced("lm_head_verify")
     def lm_head_verify(self, hidden, weight, tok, lp_d, u, inv_temperature: float = 1.0):
         """N2: verify from hidden states [n,K,D] and the [V,D] lm_head matrix (logits stay in MFMA accumulators)."""
         B, K = tok.shape
-        r = self._lm_head(weight, B, K)(hidden, tok, lp_d, u, inv_temperature=inv_temperature)
+        ver = self._lm_head(weight, B, K)
+        nbytes = weight.numel() * weight.element_size() + B * K * weight.shape[1] * weight.element_size()
+        r = self._timed_step("asd_lm_head_verify", nbytes, lambda: ver(hidden, tok, lp_d, u, inv_temperature=inv_temperature))
         return r.lp_target, r.accept, r.n_acc, r.accept_bits
 
     # -- the rest of a tier step (serving/hierarchy.py): stop decision, proposal, commit draw, bookkeeping
@@ -140,6 +178,7 @@ class HipOps:
         """predictor: MinimalQualityPredictor-like (weights_numpy / input_dim / hidden_dim) -> opaque handle."""
         return (self.K.pack_mlp_weights(*predictor.weights_numpy(), device=device), predictor.input_dim, predictor.hidden_dim)
 
+    @traced("predictor_stop")
     def predictor_stop(self, pred, lp, feat, p_hist, stage_idx, costs, lam, risk_adjustment=True, n_obs=100, alpha=1.0,
                        beta=1.0, stats_col=5):
         """asd_predictor_stop on [n] sequences: p_hist [n,L] f64 is updated in place (column stage_idx) and returned
@@ -158,19 +197,23 @@ class HipOps:
             s = self._ws[key] = cls(B, V, dtype, device)
         return s
 
+    @traced("draft_sample")
     def draft_sample(self, logits, r, inv_temperature: float = 1.0, top_p: float = 1.0):
         """X1: logits [B,V] -> (tok i32 [B], log q(tok) f32 [B], nucleus threshold f32 [B])."""
         d = self._sampler("draft", logits.shape[0], logits.shape[1], logits.dtype, logits.device)(logits, r, inv_temperature, top_p)
         return d.tok, d.lp, d.thr
 
+    @traced("residual_sample")
     def residual_sample(self, t_logits, d_logits, n_acc, r, bonus, inv_temperature: float = 1.0, d_threshold=None):
         """t_logits / d_logits [n,K,V], bonus [n,V], n_acc i32 [n], r f32 [n] -> committed token i32 [n]."""
         s = self._sampler("residual", t_logits.shape[0], t_logits.shape[2], t_logits.dtype, t_logits.device)
         return s(t_logits, d_logits, n_acc, r, bonus, inv_temperature, d_threshold=d_threshold)
 
+    @traced("commit_step")
     def commit_step(self, tok, n_acc, drawn, seq_len, tokens, n_commit, max_len):
         self.K.commit_step(tok, n_acc, drawn, seq_len, tokens, n_commit, max_len=max_len)
 
+    @traced("lambda_sweep")
     def lambda_sweep(self, p_hist, costs, lams):
         """N4: the DP rule for every (lambda, sequence) pair in one launch -> k_star [G, n] i32."""
         return self.K.lambda_sweep(p_hist, costs, lams)[0]

@@ -14,12 +14,15 @@ What the reference's loop does per request (pipeline.py:165-286), and what this 
                      k*  = optimal_stopping_rule(p[:i+1], C[:i+1], lambda)            :251-256
                      stop when k* == i, else prompt_{i+1} = prompt + " " + output     :259-266
 
-`batch_process` really batches (the reference leaves it as a TODO, :331-338: "intelligent batching based on
+`batch_process` really batches: all still-active requests of a stage go through ONE stage.generate call, ONE Bayes
+launch and ONE DP launch (`batch_grouping="none"`, the default: one batch, as the reference's call shape implies).
+Opt-in `batch_grouping="predicted_stage"` implements the reference's TODO (:331-338: "intelligent batching based on
 predicted stages"): the predictor is asked for every request's acceptance probability at every stage from the
 PROMPT alone, ONE DP launch over [n, L] turns that into a predicted stop stage, requests are grouped by it and the
 groups run shallowest first (a group's requests leave the cascade together, so the stage calls of a group stay
-full and easy requests are not held back by hard ones).  Inside a group all still-active requests of a stage go
-through ONE stage.generate call, ONE Bayes launch and ONE DP launch.  `batch_grouping="none"` keeps one group.
+full and easy requests are not held back by hard ones; but it means up to L stage-0 calls on smaller batches and
+n * (L - 1) prompt-only predictor calls up front -- one per stage with a predictor that offers `predict_batch` -- so it
+is not the default).
 
 stop_rule:
   "prefix" -- the reference's rule verbatim.  Because the DP is run on the prefix p[:i+1], and a
@@ -64,7 +67,7 @@ class PipelineConfig:
     stop_rule: str = "full"                                 # "full" | "prefix" (see module docstring)
     stage_names: Sequence[str] = DEFAULT_STAGE_NAMES
     stage_priors: Optional[Sequence[float]] = None          # prior p for not-yet-run stages ("full")
-    batch_grouping: str = "predicted_stage"                 # batch_process: "predicted_stage" | "none"
+    batch_grouping: str = "none"                            # batch_process: "none" (one batch, the reference's shape) | "predicted_stage"
 
     @classmethod
     def from_yaml(cls, path: str) -> "PipelineConfig":
@@ -185,10 +188,15 @@ class AdaptiveSpeculativePipeline:
         names = list(cfg.stage_names)
         L = len(names)
         P = np.ones((len(prompts), L), dtype=np.float64)
-        for j, prompt in enumerate(prompts):
-            for i in range(L - 1):
-                P[j, i] = float(self.predictor.predict(prompt=prompt, draft_output="", draft_logprobs=None, stage_id=i,
-                                                       feature_extractor=self.feature_extractor))
+        batched = getattr(self.predictor, "predict_batch", None)
+        for i in range(L - 1):
+            if batched is not None:                                     # ONE predictor forward per stage for the whole batch
+                P[:, i] = np.asarray(batched(prompts=list(prompts), draft_outputs=[""] * len(prompts), draft_logprobs=None,
+                                             stage_id=i, feature_extractor=self.feature_extractor), dtype=np.float64)
+            else:                                                       # the reference's per-request predictor interface
+                for j, prompt in enumerate(prompts):
+                    P[j, i] = float(self.predictor.predict(prompt=prompt, draft_output="", draft_logprobs=None, stage_id=i,
+                                                           feature_extractor=self.feature_extractor))
         backend = get_backend()
         if cfg.risk_adjustment:
             with self._stats_lock:
@@ -218,7 +226,17 @@ class AdaptiveSpeculativePipeline:
         if self.cache_manager:
             stats["cache_stats"] = self.cache_manager.get_stats()
         stats["active_requests"] = len(self.active_requests)
+        # telemetry of the token-level hot path behind the stages, when one is attached ("keep get_stats() keys;
+        # add hbm_gbps, kernel_us"): the last verify step of a profiling HipOps
+        hot = getattr(self, "hot_path_ops", None)
+        if hot is not None:
+            stats.update({k: v for k, v in hot.stats().items() if k in ("kernel_us", "hbm_gbps")})
         return stats
+
+    def attach_hot_path(self, ops) -> None:
+        """ops: the distributed.HipOps (profile=True) the stages verify with; get_stats() then carries `kernel_us` and
+        `hbm_gbps` of its last verify step."""
+        self.hot_path_ops = ops
 
     def reset_stats(self):
         with self._stats_lock:

@@ -240,11 +240,13 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
     L = len(shp)
     red = torch.device("cpu") if (world > 1 and dist.get_backend() == "gloo") else device   # gloo: one-GPU rehearsal
 
+    ctrl = {"c": None}                                   # the running lambda controller (created after the probe step)
+
     def run(n):
         if world == 1:
-            return H.generate_hierarchical(draft, [tiers[s] for s in range(1, L)], max_steps=n)
+            return H.generate_hierarchical(draft, [tiers[s] for s in range(1, L)], max_steps=n, controller=ctrl["c"])
         return H.run_hierarchical_rank(rank, pl, draft, tiers, B, K, L, V, torch.bfloat16, prompt_len + new_tokens, device,
-                                       max_steps=n)
+                                       max_steps=n, controller=ctrl["c"])
 
     def barrier():
         if world > 1:
@@ -274,10 +276,21 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
             role.cfg.lambda_value = lam_v
         cfg.lambda_value = lam_v
         calib = {"target_tier1_stop_rate": target_stop_rate, "probe_share": share,
-                 "how": "one probe step at lambda=1e6, then asd_lambda_sweep over 256 log-spaced lambdas on the probe's p_hist"}
+                 "how": "one probe step at lambda=1e6, asd_lambda_sweep over 256 log-spaced lambdas on the probe's p_hist; then a "
+                        "RUNNING controller (hierarchy.StopRateController): after every step the same sweep over the p_hist rows "
+                        "tier 1 judged during the last 4 steps re-solves lambda for the target share"}
+        if 1 in tiers and rank == pl.leader(1):
+            ctrl["c"] = H.StopRateController(ops, tiers[1].cfg, tiers[1].costs, 1, target_stop_rate, window=4, every=1)
+            ctrl["c"].observe(tr0.records[0]["tiers"][1][0].p_hist)
     if active and warmup:
         run(warmup)
     ops.totals_ms()
+    roles = ([draft] if draft is not None else []) + [tiers[k_] for k_ in sorted(tiers)]
+    for role in roles:
+        role.events = []                                 # HIP events around every model pass (per-tier torch time)
+        role.fwd_calls = 0
+        if hasattr(role, "fwd_positions"):
+            role.fwd_positions = 0
     for t in tiers.values():
         t.fed_tokens = 0
     barrier()
@@ -292,9 +305,45 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
         t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    model_ms = {}
+    for role in roles:
+        name = "tier0_draft" if role is draft else f"tier{role.s}"
+        model_ms[name] = {"ms": sum(a.elapsed_time(b_) for a, b_ in role.events), "passes": len(role.events)}
+        role.events = None
     if rank != pl.draft:
         return None
     hot_ms = sum(v[0] for v in hot.values())
+    # ---- roofline of the LOOP step (north star: "absolute numbers and fraction of HBM roofline"): the bytes a step cannot
+    # avoid streaming from HBM -- every model pass reads its tier's weights once (all parameters but the embedding table,
+    # of which only the fed rows are touched), the K/V of the sequences it attends over, and the logits it writes and the
+    # hot path reads back -- over the measured step time, against the 8 TB/s peak.  Counted for the roles THIS rank hosts.
+    def stream_bytes(model):
+        total = sum(p_.numel() * p_.element_size() for p_ in model.parameters())
+        return total - model.embed.weight.numel() * model.embed.weight.element_size()
+    esz = 2
+    per_tier = {}
+    ctx = prompt_len + (warmup + steps // 2) * (K + 1) * 0.6            # mean context length of the timed region (approx.)
+    loop_bytes = 0.0
+    for i_, role in enumerate(roles):
+        shp_ = role.m.shape
+        wbytes = stream_bytes(role.m)
+        passes = tr.tier_forwards[0] if role is draft else tr.tier_forwards[role.s]
+        positions = tr.tier_forward_positions[0] if role is draft else tr.tier_forward_positions[role.s]
+        seqs = positions / (1 if role is draft else (K + 1))             # sequences attended over, summed over passes
+        kv = 2.0 * shp_.layers * shp_.kv_heads * shp_.head_dim * ctx * esz * (positions if role is draft else seqs)
+        logits = 2.0 * positions * V * esz                               # written by the lm_head GEMM, read by the hot path
+        if not role is draft and heads[min(role.s - 1, len(heads) - 1)] == "fused":
+            logits = 0.0                                                 # asd_lm_head_verify: the logits never reach HBM
+        b_ = passes * wbytes + kv + logits
+        loop_bytes += b_
+        per_tier["tier0_draft" if role is draft else f"tier{role.s}"] = {
+            "weights_GB": wbytes / 1e9, "passes": passes, "positions": positions, "bytes_GB": b_ / 1e9,
+            "floor_ms_at_8TBs": 1e3 * b_ / 8e12, "model_ms": model_ms.get("tier0_draft" if role is draft else f"tier{role.s}", {}).get("ms")}
+    loop_roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": loop_bytes / elapsed / 1e9,
+                 "frac": loop_bytes / elapsed / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": loop_bytes / max(1, tr.steps),
+                 "floor_ms_per_step_at_8TBs": 1e3 * loop_bytes / max(1, tr.steps) / 8e12, "per_tier": per_tier,
+                 "what": "bytes of every model pass (weights once per pass + K/V attended + logits written and re-read) / step time; "
+                         "model execution is torch plumbing (third party in the reference), the hot-path kernels are `hot_path_calls`"}
     rec = {
         "tiers": [s.name for s in shp], "placement": {"draft": pl.draft, "tiers": pl.tiers, "ranks": world},
         "heads": list(heads), "batch": B, "draft_len": K, "prompt_len": prompt_len, "steps": tr.steps, "warmup": warmup,
@@ -306,6 +355,8 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
         "hot_path_ms_per_step_on_draft_rank": hot_ms / max(1, tr.steps),
         "hot_path_calls": {k: {"ms": v[0], "calls": v[1]} for k, v in hot.items()},
         "hot_path_share": hot_ms / (1e3 * elapsed), "build_s": build_s,
+        "roofline": loop_roof, "model_ms": model_ms,
+        "lambda_history": tr.lambda_history, "tier_forwards": tr.tier_forwards,
         "models": "synthetic random-weight Qwen2.5 shapes (torch / hipBLASLt; third-party in the reference), logit_scale "
                   f"{logit_scale} so that unrelated random models still accept tokens; KV per sequence (ragged)",
     }
@@ -805,7 +856,7 @@ def main():
                          "lm_head is vocab-sharded over all ranks ([B,K,3] all-gather per step); weak scaling")
     ap.add_argument("--tier-shapes", default="7b,32b,72b", help="Qwen2.5 shapes of the tiers (or tiny,tiny,tiny)")
     ap.add_argument("--loop-batch", type=int, default=32)
-    ap.add_argument("--loop-steps", type=int, default=6, help="steps of the bounded `loop` sub-record of the default run")
+    ap.add_argument("--loop-steps", type=int, default=12, help="steps of the bounded `loop` sub-record of the default run")
     ap.add_argument("--no-loop", action="store_true", help="skip the bounded 7B/32B/72B loop sub-record")
     ap.add_argument("--lam", type=float, default=None, help="lambda of the loop (default: calibrated to --stop-rate)")
     ap.add_argument("--stop-rate", type=float, default=0.66, help="target share of blocks whose tier-1 verdict is final "

@@ -143,3 +143,29 @@ def test_packed_lm_head_follows_an_in_place_weight_update():
     a, b = both(half)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert len(packed_ops._packed) == 2 and {k[1] for k in packed_ops._packed} == {(V, D), (V // 2, D)}
+
+
+def test_get_stats_reports_the_last_verify_step_and_roctx_ranges_are_live():
+    """get_stats() keeps the reference's keys (pipeline.py:346-370) and gains `kernel_us` / `hbm_gbps` of the last
+    verify step of an attached, profiling HipOps; the hot-path calls run inside roctx ranges."""
+    import torch
+    from asd_amd import trace
+    from asd_amd.distributed import HipOps
+    from asd_amd.serving import AdaptiveSpeculativePipeline, PipelineConfig
+    from tests.test_host_logic import FakeStageManager, ScriptedPredictor
+    assert trace.enabled()                                       # torch.cuda.nvtx == roctx on this build
+    c = make_verify_case(32, 8, 152064, O.DT_BF16, seed=4)
+    lg = to_device_logits(c["logits"], c["dtype"]).view(32, 8, 152064)
+    tok, lp_d, u = (torch.from_numpy(c[k]).cuda() for k in ("tok", "lp_d", "u"))
+    ops = HipOps(profile=True)
+    pipe = AdaptiveSpeculativePipeline(FakeStageManager(), ScriptedPredictor(), object(), PipelineConfig())
+    assert "kernel_us" not in pipe.get_stats()
+    pipe.attach_hot_path(ops)
+    for _ in range(50):
+        out = ops.verify_accept(lg, tok, lp_d, u)
+    st = pipe.get_stats()
+    for key in ("total_requests", "stage_distribution", "avg_tokens_per_request", "active_requests"):     # the reference's keys
+        assert key in st
+    assert 5.0 < st["kernel_us"] < 200.0 and 400.0 < st["hbm_gbps"] < 8000.0, st
+    assert np.array_equal(out[1].cpu().numpy(), c["ref"]["accept"])
+    pipe.shutdown()

@@ -297,7 +297,8 @@ def test_batch_process_groups_requests_by_predicted_stop_stage():
     prompts = ["easy a", "hard a", "mid a", "hard b", "easy b", "mid b", "hard c"]
     plain, _ = _pipeline("full", lam=30.0, risk_adjustment=False, batch_grouping="none")
     want = plain.batch_process(prompts)
-    pipe, sm = _pipeline("full", lam=30.0, risk_adjustment=False)
+    assert plain.config.batch_grouping == "none" and _pipeline("full")[0].config.batch_grouping == "none"   # grouping is opt-in
+    pipe, sm = _pipeline("full", lam=30.0, risk_adjustment=False, batch_grouping="predicted_stage")
     pred = pipe.predict_stop_stages(prompts)
     costs = [1.0, 1.6, 4.2, 8.8]
     for word, k in zip((p.split()[0] for p in prompts), pred):
@@ -314,6 +315,21 @@ def test_batch_process_groups_requests_by_predicted_stop_stage():
     sizes = sorted(len(c) for c in sm.stages["8b"].calls)
     assert sizes == sorted(int((pred == s).sum()) for s in set(pred.tolist()))
     assert [len(c) for c in sm.stages["8b"].calls] == [int((pred == s).sum()) for s in sorted(set(pred.tolist()))]
+    # a predictor with a batch interface is asked ONCE per stage for the whole batch
+    class BatchedPredictor(ScriptedPredictor):
+        def __init__(self):
+            super().__init__()
+            self.batch_calls = 0
+
+        def predict_batch(self, prompts, draft_outputs, draft_logprobs, stage_id, feature_extractor):
+            self.batch_calls += 1
+            return [min(0.99, {"easy": 0.97, "mid": 0.6, "hard": 0.05}.get(p.split()[0], 0.5) + 0.2 * stage_id) for p in prompts]
+    bp = BatchedPredictor()
+    both = AdaptiveSpeculativePipeline(FakeStageManager(), bp, object(),
+                                       PipelineConfig(lambda_value=30.0, stop_rule="full", risk_adjustment=False,
+                                                      batch_grouping="predicted_stage"))
+    assert np.array_equal(both.predict_stop_stages(prompts), pred) and bp.batch_calls == 3 and bp.calls == 0
+    both.shutdown()
     plain.shutdown()
     pipe.shutdown()
 
