@@ -239,6 +239,12 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
     build_s = time.perf_counter() - t0
     L = len(shp)
     red = torch.device("cpu") if (world > 1 and dist.get_backend() == "gloo") else device   # gloo: one-GPU rehearsal
+    graphs_on = os.environ.get("ASD_LOOP_GRAPHS", "1") != "0"
+    if graphs_on:
+        # plumbing: the draft's one-token passes and tier 1's full-batch pass replay from hipGraphs (an eager 7B pass is
+        # ~1500 launches); subset feeds (tier 2 sees only the escalated sequences) stay eager
+        for role in ([draft] if draft is not None else []) + [tiers[k_] for k_ in sorted(tiers) if k_ == 1]:
+            role.m.enable_graphs(True)
 
     ctrl = {"c": None}                                   # the running lambda controller (created after the probe step)
 
@@ -355,7 +361,7 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
         "hot_path_ms_per_step_on_draft_rank": hot_ms / max(1, tr.steps),
         "hot_path_calls": {k: {"ms": v[0], "calls": v[1]} for k, v in hot.items()},
         "hot_path_share": hot_ms / (1e3 * elapsed), "build_s": build_s,
-        "roofline": loop_roof, "model_ms": model_ms,
+        "roofline": loop_roof, "model_ms": model_ms, "model_passes_from_hipgraphs": graphs_on,
         "lambda_history": tr.lambda_history, "tier_forwards": tr.tier_forwards,
         "models": "synthetic random-weight Qwen2.5 shapes (torch / hipBLASLt; third-party in the reference), logit_scale "
                   f"{logit_scale} so that unrelated random models still accept tokens; KV per sequence (ragged)",

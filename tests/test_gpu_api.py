@@ -226,3 +226,33 @@ def test_ragged_loop_commits_per_sequence_and_matches_oracle():
     assert total == tr.verified_tokens == B * NEW
     per_seq_steps = [sum(1 for c in tr.commits if c[b].item() > 0) for b in range(B)]
     assert tr.steps < NEW and len(set(per_seq_steps)) >= 1
+
+
+def test_forward_ragged_from_a_hipgraph_matches_the_eager_pass():
+    """Plumbing of the loop (bench.py `loop` record): SyntheticLM.enable_graphs() replays full-batch forward_ragged calls
+    from a hipGraph that attends over the whole cache.  Same logits as the eager pass (to the rounding of a longer masked
+    softmax), new inputs are honoured on every replay, subset feeds stay eager."""
+    import torch
+    from asd_amd.serving.synthetic_lm import SyntheticLM, tiny
+    B, P, cap = 4, 6, 40
+    ids = torch.randint(0, 1000, (B, P), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    outs = {}
+    for mode in ("eager", "graph"):
+        m = SyntheticLM(tiny(), dtype=torch.float32, device="cuda", seed=3)
+        m.alloc_ragged(B, cap)
+        m.forward_ragged(ids, torch.zeros((B,), dtype=torch.int64, device="cuda"), P)
+        if mode == "graph":
+            m.enable_graphs(True)
+        seq = []
+        pos = torch.full((B,), P, dtype=torch.int64, device="cuda")
+        tok = ids[:, -1:].clone()
+        for step in range(5):
+            lg = m.forward_ragged(tok, pos, P + step + 1).clone()
+            seq.append(lg)
+            tok = lg[:, -1].argmax(-1, keepdim=True)
+            pos = pos + 1
+        sub = m.forward_ragged(tok[:2], pos[:2], cap, rows=torch.tensor([0, 1], device="cuda"))     # subset: eager either way
+        outs[mode] = (torch.stack(seq), sub.clone(), len(m._graphs or {}))
+    assert outs["graph"][2] == 1 and outs["eager"][2] == 0
+    assert (outs["eager"][0] - outs["graph"][0]).abs().max().item() < 2e-4
+    assert (outs["eager"][1] - outs["graph"][1]).abs().max().item() < 2e-4
