@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: where does an asd_draft_sample launch spend its time?  Builds a SEPARATE library with -DASD_STAMP
-(gpurun_out/libasd_draft_stamp.so; the shipped library never contains stamps), runs the sampler on bench-shaped rows and
+(gpurun_out/libasd_draft_stamp.so; the shipped library never contains stamps), runs the STREAMING form of the sampler
+(k_draft_row, what B > 128 uses; the group kernel of round 3 is timed by tools/bench_sampling.py) on bench-shaped rows and
 prints the phase boundaries of workgroup 0 in microseconds (s_memrealtime, 100 MHz => 10 ns ticks):
   0 start | 1 row LSE | 2,3 histogram level 1 sweep | 4,5 level 2 | 6,7 level 3 (f32 only) | 8 threshold known |
   9 nucleus LSE | 10 tile masses | 11 token written.
@@ -28,8 +29,9 @@ def main():
     lib_path = os.path.join(out, "libasd_draft_stamp.so")
     csrc = os.path.join(ROOT, "adaptive-speculative-decoding_amd", "csrc")
     subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-DASD_STAMP",
-                           f"-I{ROOT}/include", f"-I{csrc}", os.path.join(csrc, "residual_sample.hip"), os.path.join(csrc, "api.hip"), "-o", lib_path])
+                           f"-I{ROOT}/include", f"-I{csrc}", os.path.join(csrc, "draft_sample.hip"), os.path.join(csrc, "api.hip"), "-o", lib_path])
     lib = C.CDLL(lib_path)
+    lib.asd_debug_draft_groups(-1)       # the stamps live in k_draft_row, the one-workgroup-per-row streaming form (B > 128)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(5)
     logits = (torch.randn((B, V), generator=g, device=dev) * scale).to(torch.bfloat16)
