@@ -296,6 +296,17 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     // The slots refilled after it (hidden: slot of S-1; weights: slot (S+2) % 3 = (S-1) % 3) were read into
     // registers -- k-step 3 included, see wait_and_meet's lgkmcnt(0) -- before their readers reached it.
     int S = s_begin;
+#if ASD_LMHEAD_LAB & 1
+    // lab, "math alone": no load in the loop, so EVERY ring slot is filled once with real operands up front (round 3: with one
+    // weight slot and one hidden slot left as whatever the previous kernel had in LDS the variant's time depended on that
+    // garbage -- 513 us in round 1, 1508 us under the counter passes of round 3)
+    if (S + 2 < n_super) {
+        issue_w(S + 2);
+        issue_h(S + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#endif
     if (S < n_super) {
         issue_w(S);
         issue_h(S);

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "decision_device.hpp"
+#include "lse_device.hpp"
 
 #include <math.h>
 
@@ -48,6 +49,14 @@ static __device__ double np_sum(const double* a, int n) {  // n <= 1024
     return np_sum_d2(a, h) + np_sum_d2(a + h, n - h);
 }
 
+// lane 0's double in every lane: two v_readfirstlane (scalar path) instead of the ds_bpermute pair of __shfl
+__device__ __forceinline__ double bcast_lane0(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b >> 32));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 // numpy _lerp (numpy/lib/_function_base_impl.py)
 __device__ __forceinline__ double np_lerp(double a, double b, double t) {
     const double d = b - a;
@@ -82,7 +91,7 @@ static __device__ void wave_logprob_stats_t(double* vals, double* sorted, double
     double mean = 0.0;
     // SMALL: n <= 128 is known (the in-kernel epilogue: n = K <= 64), where numpy's pairwise sum IS its leaf routine
     if (lane == 0) mean = (SMALL ? np_sum_leaf(vals, n) : np_sum(vals, n)) / static_cast<double>(n);          // np.mean :168
-    mean = __shfl(mean, 0, 64);
+    mean = bcast_lane0(mean);
     for (int i = lane; i < n; i += 64) {
         const double t = vals[i] - mean;
         sq[i] = t * t;
@@ -240,7 +249,7 @@ __device__ __forceinline__ void epi_finish(const FusedParams& p, int b, int lane
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         wave_logprob_stats(dvals, dvals + 64, dvals + 128, n, lane, st);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) st[i] = __shfl(st[i], 0, 64);
+        for (int i = 0; i < 5; ++i) st[i] = bcast_lane0(st[i]);
         if (p.stats && lane == 0) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
@@ -259,9 +268,8 @@ __device__ __forceinline__ void epi_finish(const FusedParams& p, int b, int lane
     for (int i = 0; i < 32; ++i) h = fmaf(e.w[i], xs[half * 32 + i], h);
     h += __shfl_xor(h, 32, 64);
     h = fmaxf(h + e.b1, 0.0f);
-    float z = half == 0 ? e.w2 * h : 0.0f;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) z += __shfl_xor(z, off, 64);
+    // the output unit: one DPP wave sum (fixed order; the ds_bpermute butterfly it replaces was five dependent LDS round trips)
+    const float z = wave_sum(half == 0 ? e.w2 * h : 0.0f);
     const float sc = 1.0f / (1.0f + expf(-(z + e.b2)));
     if (lane == 0) decide_and_store_impl<true>(p, b, sc, e.d);
 }
@@ -292,7 +300,7 @@ __device__ __forceinline__ void epi_finish_lds(const FusedParams& p, int b, int 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         wave_logprob_stats_t<true>(dvals, dvals + 64, dvals + 128, n, lane, st);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) st[i] = __shfl(st[i], 0, 64);
+        for (int i = 0; i < 5; ++i) st[i] = bcast_lane0(st[i]);
         if (p.stats && lane == 0) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
@@ -311,9 +319,7 @@ __device__ __forceinline__ void epi_finish_lds(const FusedParams& p, int b, int 
     for (int i = 0; i < 32; ++i) h = fmaf(wl[(half * 32 + i) * 32 + j], xs[half * 32 + i], h);
     h += __shfl_xor(h, 32, 64);
     h = fmaxf(h + wl[64 * 32 + j], 0.0f);
-    float z = half == 0 ? wl[64 * 32 + 32 + j] * h : 0.0f;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) z += __shfl_xor(z, off, 64);
+    const float z = wave_sum(half == 0 ? wl[64 * 32 + 32 + j] * h : 0.0f);      // (same DPP order as epi_finish: bit-identical scores)
     const float sc = 1.0f / (1.0f + expf(-(z + wl[64 * 32 + 64])));
     if (lane == 0) decide_and_store_small(p, b, sc, e.d);
 }

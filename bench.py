@@ -158,7 +158,8 @@ def load_traffic():
     """HBM bytes per verify launch from the last committed PMC pass (profiles/*traffic.json), or None."""
     pdir = os.path.join(ROOT, "profiles")
     try:
-        cands = sorted(f for f in os.listdir(pdir) if f.endswith("traffic.json"))
+        import re
+        cands = sorted(f for f in os.listdir(pdir) if re.fullmatch(r"r\d+_traffic\.json", f))   # the PLAIN kernel's record of the latest round
     except OSError:
         return None, None
     if not cands:

@@ -57,12 +57,25 @@ for v, d in per_pass.items():
     ns = sum(d["ns_mean_by_pass"]) / len(d["ns_mean_by_pass"])
     rec = {"wide_launch_us": ns / 1e3, "launches_per_pass": d["launches"], "counters": {k: val for k, val in d.items() if k.isupper()}}
     if "GRBM_GUI_ACTIVE" in d:
-        rec["clock_GHz_gui_active"] = d["GRBM_GUI_ACTIVE"] / ns
+        # the counter is reported summed over the chip's 8 XCDs (each XCD's GRBM counts its own shader-clock cycles)
+        rec["gui_active_cycles_per_ns_all_xcds"] = d["GRBM_GUI_ACTIVE"] / ns
+        rec["clock_GHz"] = d["GRBM_GUI_ACTIVE"] / ns / 8.0
     if "SQ_WAVE_CYCLES" in d and "SQ_WAVES" in d and d["SQ_WAVES"]:
         rec["wave_cycles_per_wave_x4"] = 4.0 * d["SQ_WAVE_CYCLES"] / d["SQ_WAVES"]
     if "SQ_BUSY_CYCLES" in d:
         rec["sq_busy_cycles"] = d["SQ_BUSY_CYCLES"]
     out["variants"][v] = rec
+try:
+    with open(os.path.join(O, "lab_unprofiled.json")) as f:
+        out["unprofiled_call_us"] = {r["variant"]: r["us"] for r in json.load(f)}
+except OSError:
+    pass
+v = out["variants"]
+if all(k in v and "clock_GHz" in v[k] for k in VARIANTS):
+    c = {k: v[k]["clock_GHz"] for k in VARIANTS}
+    out["reading"] = {"clock_GHz": c, "combined_vs_loads_only": c["base"] / c["nomath"], "combined_vs_math_only": c["base"] / c["noload"],
+                      "rule": "VERDICT r2 item 7: the combined kernel's clock >= 10 % below BOTH singles => the chip's power management, not "
+                              "the schedule, is the limiter at M = 256"}
 print(json.dumps(out, indent=1))
 with open(os.path.join(O, "summary.json"), "w") as f:
     json.dump(out, f, indent=1)

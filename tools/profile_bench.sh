@@ -16,10 +16,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T
 cd $R
 python3 tools/kstats.py $O/${T}_prof_stats --top 8
 python3 tools/kstats.py $O/${T}_prof_sampling --top 8
-F=$(ls $O/${T}_prof_fetch/*counter_collection.csv $O/${T}_prof_fetch/*/*counter_collection.csv 2>/dev/null | head -1)
-W=$(ls $O/${T}_prof_write/*counter_collection.csv $O/${T}_prof_write/*/*counter_collection.csv 2>/dev/null | head -1)
+F=$(find $O/${T}_prof_fetch -name "*counter_collection.csv" | head -1)
+W=$(find $O/${T}_prof_write -name "*counter_collection.csv" | head -1)
 python3 tools/parse_pmc.py --fetch $F --write $W --kernel "512, 3, true, false, false" --out $O/${T}_traffic.json || python3 tools/parse_pmc.py --fetch $F --write $W --kernel k_verify --out $O/${T}_traffic.json
 python3 tools/parse_pmc.py --fetch $F --write $W --kernel "512, 3, true, true, false" --out $O/${T}_traffic_fused.json || true
-cp $(ls $O/${T}_prof_stats/*kernel_stats.csv $O/${T}_prof_stats/*/*kernel_stats.csv 2>/dev/null | head -1) $O/${T}_kernel_stats.csv
-cp $(ls $O/${T}_prof_sampling/*kernel_stats.csv $O/${T}_prof_sampling/*/*kernel_stats.csv 2>/dev/null | head -1) $O/${T}_sampling_kernel_stats.csv
+cp $(find $O/${T}_prof_stats -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats.csv
+cp $(find $O/${T}_prof_sampling -name "*kernel_stats.csv" | head -1) $O/${T}_sampling_kernel_stats.csv
 tail -c 600 $O/${T}_bench_under_rocprof.json

@@ -10,6 +10,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03_lmh_clock
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 python3 $R/tools/lm_head_lab.py --run --shapes 72b --reps 10 --out $O/lab_unprofiled.json > $O/unprofiled.log 2>&1 || echo "unprofiled lab run failed"
 i=0
 for P in "GRBM_GUI_ACTIVE GRBM_COUNT" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
