@@ -240,10 +240,11 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
     build_s = time.perf_counter() - t0
     L = len(shp)
     red = torch.device("cpu") if (world > 1 and dist.get_backend() == "gloo") else device   # gloo: one-GPU rehearsal
-    graphs_on = os.environ.get("ASD_LOOP_GRAPHS", "1") != "0"
+    graphs_on = os.environ.get("ASD_LOOP_GRAPHS", "0") == "1"
     if graphs_on:
-        # plumbing: the draft's one-token passes and tier 1's full-batch pass replay from hipGraphs (an eager 7B pass is
-        # ~1500 launches); subset feeds (tier 2 sees only the escalated sequences) stay eager
+        # plumbing experiment (off by default): the draft's one-token passes and tier 1's full-batch pass replayed from
+        # hipGraphs.  Measured in round 3: 15.0 ms instead of 15.9 ms per 7B pass -- the passes are NOT launch-bound, they are
+        # bound by the library's skinny GEMMs (M = 32: 14.1 GB of weights in 15 ms = 0.94 TB/s); see DESIGN.md section 6
         for role in ([draft] if draft is not None else []) + [tiers[k_] for k_ in sorted(tiers) if k_ == 1]:
             role.m.enable_graphs(True)
 
