@@ -186,52 +186,25 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     const int row = static_cast<int>(blockIdx.x);
     const int split = static_cast<int>(blockIdx.y);
 
-    // ---- the shortest possible path to the first loads (round 3).  At a cold start every instruction-cache line between the
-    // wave's entry and its first buffer_load is a ~0.4 us miss, and nothing streams before it: the stamped builds put the first
-    // loads 2.2-2.9 us after the workgroup's start at every batch size.  So the code in front of them is what the descriptor
-    // needs and nothing else (row base as a 32 x 32 -> 64-bit product -- the launcher checks ld_row < 2^31 --, the alignment
-    // peel, the slice bounds); the token load, the tile counter and every flag come BEHIND them (sched_barrier pins that).
-    const char* rowp = static_cast<const char*>(a_logits) +
-                       static_cast<int64_t>(static_cast<uint64_t>(static_cast<uint32_t>(row)) * static_cast<uint32_t>(a_ld_row)) * E::kBytes;
+    const char* rowp = static_cast<const char*>(a_logits) + static_cast<int64_t>(row) * a_ld_row * E::kBytes;
     const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(rowp) & 15u);
     int head = mis ? static_cast<int>((16u - mis) / E::kBytes) : 0;
     if (head > a_V) head = a_V;
-    const int nvec = static_cast<int>(static_cast<uint32_t>(a_V - head) / static_cast<uint32_t>(E::kPerVec));
+    const int nvec = (a_V - head) / E::kPerVec;
     const int tail = a_V - head - nvec * E::kPerVec;
     const char* body = rowp + static_cast<int64_t>(head) * E::kBytes;
     int v0 = 0, v1 = nvec;
-    if (__builtin_expect(S > 1, 0)) {   // launcher: V * S < 2^31, so the products fit 32 bits; out of line: the two divisions are ~40 instructions
+    if (S > 1) {   // launcher: V * S < 2^31, so the products fit 32 bits
         v0 = static_cast<int>(static_cast<uint32_t>(nvec) * static_cast<uint32_t>(split) / static_cast<uint32_t>(S));
         v1 = static_cast<int>(static_cast<uint32_t>(nvec) * static_cast<uint32_t>(split + 1) / static_cast<uint32_t>(S));
     }
-    // ---- streaming: waves claim UNROLL-KiB tiles from an LDS counter ---------------------------
-    // Static striding lets the oldest wave group run ahead (age-priority arbitration: measured
-    // stream ends 11.9 / 12.6 / 13.4 / 14.6 us for the four groups of a 1024-lane workgroup), so
-    // the CU's memory pipe idles while the youngest waves drain alone.  With dynamic claims all
-    // waves end within one tile of each other.  Determinism is kept by construction: every tile
-    // is reduced to its OWN (m2, s) slot, and slots are combined in tile order afterwards, so the
-    // result does not depend on which wave processed which tile.
-    constexpr uint32_t kTileBytes = static_cast<uint32_t>(UNROLL) * 1024u;
-    const uint32_t end = v1 > v0 ? static_cast<uint32_t>(v1 - v0) * 16u : 0u;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(body) + static_cast<int64_t>(v0) * 16, 0, static_cast<int>(end), 0x00020000);
-    const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
-    uint32_t ta = static_cast<uint32_t>(wave), tb = static_cast<uint32_t>(wave) + kWaves;
-    u32x4 ra[UNROLL], rb[UNROLL];
-#pragma unroll
-    for (int j = 0; j < UNROLL; ++j) ra[j] = load16<NT>(rsrc, ta * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
-#pragma unroll
-    for (int j = 0; j < UNROLL; ++j) rb[j] = load16<NT>(rsrc, tb * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
-    __builtin_amdgcn_sched_barrier(0);   // nothing below is scheduled in front of the tile loads
-    const uint32_t n_tiles = (end + kTileBytes - 1) / kTileBytes;   // launcher: n_tiles + 1 <= kMaxStage
-    const uint32_t n_full = end / kTileBytes;
-    if (tid == 0) next_tile = 2u * kWaves;
 
-    // the row's own scalars, fetched by lane 0 under the stream.  Every one of these small loads is ISSUED early and
-    // CONSUMED after the streaming loop (the compiler waits at the first use, and the loop's LDS atomics keep it from
-    // sinking the loads).  Nothing before the barrier below waits for memory: the earlier form converted the gathered logit
-    // on the spot, which put an `s_waitcnt vmcnt(0)` in front of the barrier -- wave 0 sat there until its first two tiles
-    // AND the gather had landed, and with it every wave of the workgroup (stamps: first tile consumed 4.2 us after the start).
+    // the row's own scalars, fetched by lane 0 under the stream (one workgroup per row only).  Every one of these
+    // small loads is ISSUED early and CONSUMED after the streaming loop (the compiler waits at the first use, and the
+    // loop's LDS atomics keep it from sinking the loads).  Nothing before the barrier below waits for memory: the
+    // earlier form converted the gathered logit on the spot, which put an `s_waitcnt vmcnt(0)` in front of the
+    // barrier -- wave 0 sat there until its first two tiles AND the gather (queued behind the whole CU's initial
+    // requests) had landed, and with it every wave of the workgroup (stamps: first tile consumed 4.2 us after the start).
     const bool own_row = a_own != 0;   // launcher: (S == 1) && (mode == 1 || K <= kFastMaxK)
     float x_tok = -INFINITY, lpd = 0.0f, uu = 1.0f;
     uint32_t raw_tok = 0, raw_lpd = 0, raw_u = 0x3f800000u, raw_x = 0;
@@ -244,7 +217,29 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     // split rows: slice 0 of a row fetches the drafted token's logit under its stream and hands it to the finisher (round 2: the
     // finisher loaded tok, then the logit -- two dependent round trips on the tail of every sequence)
     const bool gather = own_row || split == 0;
-    if (gather && tid == 0) raw_tok = static_cast<uint32_t>(a_tok[vrow]);
+    if (gather && tid == 0) raw_tok = static_cast<uint32_t>(a_tok[vrow]);   // the oldest load of wave 0: waited for alone
+
+    // ---- streaming: waves claim UNROLL-KiB tiles from an LDS counter ---------------------------
+    // Static striding lets the oldest wave group run ahead (age-priority arbitration: measured
+    // stream ends 11.9 / 12.6 / 13.4 / 14.6 us for the four groups of a 1024-lane workgroup), so
+    // the CU's memory pipe idles while the youngest waves drain alone.  With dynamic claims all
+    // waves end within one tile of each other.  Determinism is kept by construction: every tile
+    // is reduced to its OWN (m2, s) slot, and slots are combined in tile order afterwards, so the
+    // result does not depend on which wave processed which tile.
+    constexpr uint32_t kTileBytes = static_cast<uint32_t>(UNROLL) * 1024u;
+    const uint32_t end = v1 > v0 ? static_cast<uint32_t>(v1 - v0) * 16u : 0u;
+    const uint32_t n_tiles = (end + kTileBytes - 1) / kTileBytes;   // launcher: n_tiles + 1 <= kMaxStage
+    const uint32_t n_full = end / kTileBytes;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(body) + static_cast<int64_t>(v0) * 16, 0, static_cast<int>(end), 0x00020000);
+    const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
+    if (tid == 0) next_tile = 2u * kWaves;
+    uint32_t ta = static_cast<uint32_t>(wave), tb = static_cast<uint32_t>(wave) + kWaves;
+    u32x4 ra[UNROLL], rb[UNROLL];
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) ra[j] = load16<NT>(rsrc, ta * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) rb[j] = load16<NT>(rsrc, tb * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
     ASD_STAMP_AT(7);
     __syncthreads();   // next_tile is visible; the first two tiles of every wave are already in flight
 
@@ -650,7 +645,6 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     if (esz == 0) return ASD_ERR_UNSUPPORTED;
     if (!p.logits || !p.tok || !workspace) return ASD_ERR_INVALID_ARG;
     if (p.ld_row < p.V) return ASD_ERR_INVALID_ARG;
-    if (p.ld_row > INT32_MAX) return ASD_ERR_UNSUPPORTED;        // the kernel forms row * ld_row as a 32 x 32 -> 64-bit product
     if (!aligned_to(p.logits, static_cast<size_t>(esz))) return ASD_ERR_ALIGNMENT;
     if (!aligned_to(workspace, 256)) return ASD_ERR_WORKSPACE;
     const int64_t R = static_cast<int64_t>(p.B) * p.K;
