@@ -42,8 +42,13 @@ def main():
         inv_t = float(np.float32(1.0 / T))
         ref = O.draft_sample(store, dtype, r, B, V, inv_t, top_p)
         lg = to_device_logits(store, dtype).view(B, V)
-        d = K.DraftSampler(B, V, lg.dtype)(lg, torch.from_numpy(r).cuda(), inv_t, top_p)
+        groups = int(rng.choice([0, 0, -1, 1, 2, 4, 8, 16, 32]))            # 0: heuristic; -1: the streaming form; else forced
+        K._lib().asd_debug_draft_groups(groups if groups <= 0 or B * groups <= 256 else 0)
+        samp = K.DraftSampler(B, V, lg.dtype)
+        d = samp(lg, torch.from_numpy(r).cuda(), inv_t, top_p)
         torch.cuda.synchronize()
+        K._lib().asd_debug_draft_groups(0)
+        assert int(samp.buf.count_nonzero()) == 0, (it, "workspace not handed back empty", B, V, groups)
         tok, lp, thr = d.tok.cpu().numpy(), d.lp.cpu().numpy(), d.thr.cpu().numpy()
         okp = ref["margin_p"] > 1e-5
         assert np.array_equal(thr[okp], ref["thr"][okp]), (it, "thr", B, V, dtype, scale, T, top_p)
