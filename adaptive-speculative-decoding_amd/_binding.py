@@ -43,6 +43,7 @@ SIGNATURES = {
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "asd_debug_verify_withhold": (_i, [_i]),
     "asd_residual_sample_workspace_bytes": (_sz, [_i, _i, _i]),
+    "asd_debug_residual_groups": (_i, [_i]),
     "asd_residual_sample": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "asd_residual_sample_ex": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "asd_draft_sample_workspace_bytes": (_sz, [_i, _i, _i]),

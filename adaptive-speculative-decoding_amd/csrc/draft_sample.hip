@@ -49,47 +49,6 @@ struct DrParams {
 };
 
 
-// ---- pieces shared by both kernels -----------------------------------------------------------------------------------
-// The CANONICAL pair of one 64-vector tile: (M, s) with  sum over the tile of 2^(x c2) = s 2^M.  Every lane reduces its own
-// vector against its own maximum, the wave combines max-first (DPP): the value depends on the tile's bytes only, not on
-// which wave of which workgroup computes it.  A ragged last tile is padded with -inf vectors (no mass).
-template <int DT>
-__device__ __forceinline__ void tile_pair(const u32x4& vec, float c2, float& M, float& sw) {
-    constexpr int N = Elem<DT>::kPerVec;
-    float x[N];
-    unpack<DT>(vec, x);
-    float vmax = x[0];
-#pragma unroll
-    for (int i = 1; i < N; ++i) vmax = fmaxf(vmax, x[i]);
-    const float ml = fmaxf(vmax * c2, kSentinel);          // a lane of -inf logits: finite sentinel, every term 0
-    float sl = 0.0f;
-#pragma unroll
-    for (int i = 0; i < N; ++i) sl += fast_exp2(fmaf(x[i], c2, -ml));
-    M = wave_max(ml);
-    sw = wave_sum(sl * fast_exp2(ml - M));
-}
-// (m2, s) of the row from its tile pairs in a FIXED order (wave w folds tiles w, w + 16, ... one per lane, then the lanes,
-// then the 16 waves): the same bits whichever kernel / geometry produced the pairs.  All 1024 threads call it.
-__device__ __forceinline__ void fold_tile_pairs(const float* tm, const float* ts, int n_tiles, float (*red)[2], int wave, int lane,
-                                                float& m2, float& s) {
-    float wm = kSentinel, ws = 0.0f;
-    for (int tile = wave + kDrWaves * lane; tile < n_tiles; tile += kDrWaves * 64) ms_merge(wm, ws, tm[tile], ts[tile]);
-    wave_merge(wm, ws);
-    if (lane == 0) { red[wave][0] = wm; red[wave][1] = ws; }
-    __syncthreads();
-    m2 = red[0][0];
-    s = red[0][1];
-#pragma unroll
-    for (int w = 1; w < kDrWaves; ++w) ms_merge(m2, s, red[w][0], red[w][1]);
-}
-__device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
-    }
-    return v;
-}
 // ---- inverse CDF by ONE wave: prefix over the tile masses -> tile of the draw -> that tile's 64 vectors (re-read: 1 KB)
 // -> lane -> element, with the same float weights as the tile masses; log q(tok) in f64.  The prefixes are wave scans in f64
 // over f32 masses (exact unless a sum spans more than 53 bits), not 64-step loops over LDS (3.3 us of the round-2 kernel).
@@ -468,13 +427,6 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_row(const DrParams p) {
 // Because the pairs are canonical and the fold order is fixed, L -- and with it the nucleus threshold (an integer decision),
 // log q(tok) and the token -- do not depend on G: the same row gives the same bits in a batch of 8 and in a batch of 200
 // (k_draft_row, the B > 128 form, uses the same pairs, fold and draw).
-constexpr int kDgMaxGroups = 32;          // workgroups per row
-constexpr int kDgMaxLevels = 3;           // histogram rounds (f32 keys: 12 + 12 + 8 bits)
-constexpr int kDgMsgs = 1 + kDgMaxLevels; // mailbox messages per partner: (m2, s), then one decision per round
-constexpr int kDgSlots = 256;             // rows * groups the histogram exchange area is sized for (one workgroup per CU)
-constexpr int kDgSpinLimit = 1 << 19;    // polls (~1 us each) of a word whose store is in flight before the row is given up
-constexpr unsigned long long kDgValid = 1ull << 63;
-
 struct DgParams {
     DrParams d;
     int G;                    // workgroups per row
@@ -483,21 +435,6 @@ struct DgParams {
     int n_pad;                // n_tiles rounded up to a whole 256-byte block of words
     int base_shift;           // key bits that carry no information for this dtype (bf16: 16, f16: 13, f32: 0)
 };
-
-// bounded wait for a mailbox word (non-zero = published).  `lost` (LDS) is raised by the first wait that runs out and makes
-// every later wait of the workgroup return at once: a row whose partner never shows up costs ONE timeout, not one per word.
-__device__ __forceinline__ unsigned long long dg_poll(unsigned long long* slot, volatile int* lost) {
-    unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int spins = 0; v == 0ull && spins < kDgSpinLimit && !*lost; ++spins) {
-        __builtin_amdgcn_s_sleep(1);
-        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (v == 0ull) *lost = 1;
-    return v;
-}
-__device__ __forceinline__ void dg_put(unsigned long long* slot, unsigned long long v) {
-    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 template <int DT, int TPW>
 __global__ __launch_bounds__(kDrThreads) void k_draft_group(const DgParams p) {

@@ -151,48 +151,32 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_mass(const RsParams p) {
 }
 
 // ---- pass 3: inverse CDF (one wave) --------------------------------------------------------------
-// tl: the row's per-tile masses (Z, P) -- in the workspace (k_rs_pick) or in LDS (k_residual_row); Lt / Ld: the rows' normalisers
-struct RsPickScratch {
-    double chunk[64];
-    double lane_mass[64];
-    int sel_tile;
-    double sel_rest;
+// tl: the row's per-tile masses (Z, P) -- in the workspace (k_rs_pick) or in LDS (k_residual_row, k_residual_group); Lt / Ld: the
+// rows' normalisers.  Prefixes are f64 wave SCANS over f32 masses (exact unless a sum spans more than 53 bits).  Round 2 walked
+// 64-entry LDS arrays in 64-step loops (rs_pick_wave): inlined into a 1024-lane kernel that alone asked for more than the 128-VGPR
+// budget (k_residual_row spilled 24 registers) and cost ~3 us of LDS round trips on the tail.
+struct RsScanScratch {
+    int tile;
+    double rest;
 };
 template <int DT>
-__device__ __forceinline__ void rs_pick_wave(const RsParams& p, int b, int lane, const Rows<DT>& rows, const float2* tl, Norm2 Lt,
-                                             Norm2 Ld, RsPickScratch& sc) {
+__device__ __forceinline__ void rs_pick_scan(const RsParams& p, int b, int lane, const Rows<DT>& rows, const float2* tl, Norm2 Lt,
+                                             Norm2 Ld, RsScanScratch& sc) {
     using E = Elem<DT>;
     constexpr int N = E::kPerVec;
-    double (&chunk)[64] = sc.chunk;
-    double (&lane_mass)[64] = sc.lane_mass;
-    int& sel_tile = sc.sel_tile;
-    double& sel_rest = sc.sel_rest;
-    // lane l owns tiles [l*per, (l+1)*per): chunk sums of Z and of P
     const int per = (p.n_tiles + 63) / 64;
     const int c0 = lane * per, c1 = min(c0 + per, p.n_tiles);
     double cz = 0.0, cp = 0.0;
     for (int t = c0; t < c1; ++t) { cz += static_cast<double>(tl[t].x); cp += static_cast<double>(tl[t].y); }
-    // totals (fixed order through LDS)
-    chunk[lane] = cz;
-    lane_mass[lane] = cp;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double totz = 0.0, totp = 0.0;
-    for (int l = 0; l < 64; ++l) { totz += chunk[l]; totp += lane_mass[l]; }
+    const double totz = __shfl(wave_incl_scan_f64(cz, lane), 63, 64);
     const bool use_p = !(totz > 0.0);                  // empty residual (p_t <= p_d everywhere): draw from p_t
-    const double total = use_p ? totp : totz;
     const double mine = use_p ? cp : cz;
+    const double incl = wave_incl_scan_f64(mine, lane);
+    const double total = __shfl(incl, 63, 64);
+    double before = __shfl_up(incl, 1, 64);
+    if (lane == 0) before = 0.0;
     double target = static_cast<double>(p.r[b]) * total;
     if (!(target >= 0.0)) target = 0.0;
-    // exclusive prefix of chunk masses over lanes, lane of the draw
-    __builtin_amdgcn_wave_barrier();
-    chunk[lane] = mine;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double before = 0.0;
-    for (int l = 0; l < lane; ++l) before += chunk[l];
     const bool holds = mine > 0.0 && target >= before && target < before + mine;
     unsigned long long bal = __ballot(holds);
     if (bal == 0) {                                    // rounding pushed the draw past the end: last chunk with mass
@@ -200,8 +184,7 @@ __device__ __forceinline__ void rs_pick_wave(const RsParams& p, int b, int lane,
         if (bal == 0) { if (lane == 0) p.token[b] = -1; return; }
         bal = 1ull << (63 - __builtin_clzll(bal));
     }
-    const int owner = __builtin_ctzll(bal);
-    if (lane == owner) {
+    if (lane == __builtin_ctzll(bal)) {
         double acc = before;
         int pick = -1, last_pos = -1;
         for (int t = c0; t < c1; ++t) {
@@ -213,16 +196,14 @@ __device__ __forceinline__ void rs_pick_wave(const RsParams& p, int b, int lane,
             }
         }
         if (pick < 0) { pick = last_pos; acc -= static_cast<double>(use_p ? tl[pick].y : tl[pick].x); }
-        sel_tile = pick;
-        sel_rest = target - acc;
+        sc.tile = pick;
+        sc.rest = target - acc;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int tile = sel_tile;
-    const double rest = sel_rest;
-
-    // the chosen tile: the same float weights as pass 2, prefix over lanes then inside the lane
+    const int tile = sc.tile;
+    const double rest = sc.rest;
     const u32x4* vt = reinterpret_cast<const u32x4*>(rows.xt);
     const u32x4* vd = reinterpret_cast<const u32x4*>(rows.xd);
     const int v = tile * 64 + lane;
@@ -238,13 +219,9 @@ __device__ __forceinline__ void rs_pick_wave(const RsParams& p, int b, int lane,
     double lm = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) lm += static_cast<double>(use_p ? pt[i] : w[i]);
-    __builtin_amdgcn_wave_barrier();
-    lane_mass[lane] = lm;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double lb = 0.0;
-    for (int l = 0; l < lane; ++l) lb += lane_mass[l];
+    const double lincl = wave_incl_scan_f64(lm, lane);
+    double lb = __shfl_up(lincl, 1, 64);
+    if (lane == 0) lb = 0.0;
     const bool lholds = lm > 0.0 && rest >= lb && rest < lb + lm;
     unsigned long long lbal = __ballot(lholds);
     if (lbal == 0) {
@@ -271,7 +248,7 @@ __device__ __forceinline__ void rs_pick_wave(const RsParams& p, int b, int lane,
 
 template <int DT>
 __global__ __launch_bounds__(64) void k_rs_pick(const RsParams p) {
-    __shared__ RsPickScratch sc;
+    __shared__ RsScanScratch sc;
     const int b = blockIdx.x, lane = threadIdx.x;
     const Rows<DT> rows = select_rows<DT>(p, b);
     if (!rows.xt) {
@@ -280,21 +257,21 @@ __global__ __launch_bounds__(64) void k_rs_pick(const RsParams p) {
     }
     Norm2 Lt, Ld;
     row_norms(p, b, Lt, Ld);
-    rs_pick_wave<DT>(p, b, lane, rows, p.tiles + static_cast<int64_t>(b) * p.n_tiles, Lt, Ld, sc);
+    rs_pick_scan<DT>(p, b, lane, rows, p.tiles + static_cast<int64_t>(b) * p.n_tiles, Lt, Ld, sc);
 }
 
 // ---- asd_residual_sample, many sequences: ONE launch, one 1024-lane workgroup per sequence ------------------------
 // The three-launch form above cuts every row over S workgroups: right while B x S about fills the chip (B <= 32: 21-23 us),
 // but S falls to 2 at B = 128 and the three launches take 64 us.  From B = 96 on a sequence's two rows stay in ONE
 // workgroup (the structure of k_draft_row): sweep 1 = (m2, s) of the target and of the (nucleus-masked) draft row, sweep 2
-// (L2 hits) = per-tile residual / target masses into LDS, then the inverse CDF by wave 0 -- the same rs_pick_wave.
+// (L2 hits) = per-tile residual / target masses into LDS, then the inverse CDF by wave 0 -- the same rs_pick_scan.
 template <int DT>
 __global__ __launch_bounds__(kDrThreads) void k_residual_row(const RsParams p) {
     using E = Elem<DT>;
     constexpr int N = E::kPerVec;
     __shared__ float2 tiles[kDrMaxTiles];
     __shared__ float red[kDrWaves][4];
-    __shared__ RsPickScratch sc;
+    __shared__ RsScanScratch sc;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const Rows<DT> rows = select_rows<DT>(p, b);        // block-uniform
     if (!rows.xt) {
@@ -349,7 +326,149 @@ __global__ __launch_bounds__(kDrThreads) void k_residual_row(const RsParams p) {
     });
     __syncthreads();
     if (wave != 0) return;
-    rs_pick_wave<DT>(p, b, lane, rows, tiles, Lt, Ld, sc);
+    rs_pick_scan<DT>(p, b, lane, rows, tiles, Lt, Ld, sc);
+}
+
+// ---- asd_residual_sample for FEW sequences (round 3): G workgroups per sequence inside ONE launch -----------------------------
+// The structure of k_draft_group (draft_sample.hip): the sequence's target row and draft row are cut into G contiguous runs of
+// 64-vector tiles, one 1024-lane workgroup each, resident in registers (read from HBM once; the three-launch form reads them
+// twice and pays two launch gaps: 24 us at B = 32).  Per tile the CANONICAL pairs (M, s) of both rows -> the leader (workgroup 0)
+// folds them in a fixed order -> both normalisers back to the partners -> per tile the residual mass Z and the target mass P ->
+// the leader runs the same rs_pick_scan.  Mailboxes: single writer, single reader, self-tagging, handed back empty (workspace
+// all-zero between calls); a lost word poisons the sequence (token = -1).
+struct RgParams {
+    RsParams r;
+    int G, n_pad;
+    unsigned long long* small;       // per sequence: pairs_t[n_pad], pairs_d[n_pad], mass[n_pad], mail[kDgMaxGroups][2]
+};
+
+template <int DT, int TPW>
+__global__ __launch_bounds__(kDrThreads) void k_residual_group(const RgParams q) {
+    using E = Elem<DT>;
+    constexpr int N = E::kPerVec;
+    __shared__ float tm[kDrMaxTiles], ts[kDrMaxTiles], dm[kDrMaxTiles], dsum[kDrMaxTiles];
+    __shared__ float2 tiles[kDrMaxTiles];
+    __shared__ float red[kDrWaves][2];
+    __shared__ unsigned long long bc[2];
+    __shared__ volatile int lost;
+    __shared__ RsScanScratch sc;
+    const RsParams& p = q.r;
+    const int g = blockIdx.x, b = blockIdx.y, G = q.G;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool leader = g == 0;
+    const Rows<DT> rows = select_rows<DT>(p, b);            // the same for every workgroup of the sequence
+    if (!rows.xt) {
+        if (leader && t == 0) p.token[b] = -1;
+        return;
+    }
+    unsigned long long* small = q.small + static_cast<int64_t>(b) * (3 * q.n_pad + kDgMaxGroups * 2);
+    unsigned long long* pt_x = small;
+    unsigned long long* pd_x = small + q.n_pad;
+    unsigned long long* mass_x = small + 2 * q.n_pad;
+    unsigned long long* mail = small + 3 * q.n_pad + static_cast<int64_t>(g) * 2;
+    if (t == 0) lost = 0;
+    __syncthreads();
+    const u32x4* vt = reinterpret_cast<const u32x4*>(rows.xt);
+    const u32x4* vd = reinterpret_cast<const u32x4*>(rows.xd);
+    const bool has_d = vd != nullptr;
+    int t0, t1;
+    {
+        const uint32_t nt = static_cast<uint32_t>(p.n_tiles);
+        t0 = static_cast<int>(nt * static_cast<uint32_t>(g) / static_cast<uint32_t>(G));
+        t1 = static_cast<int>(nt * static_cast<uint32_t>(g + 1) / static_cast<uint32_t>(G));
+    }
+    const u32x4 neg = {E::kNegInfWord, E::kNegInfWord, E::kNegInfWord, E::kNegInfWord};
+    u32x4 qa[TPW], qb[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int tile = t0 + wave + kDrWaves * j;
+        const int v = tile * 64 + lane;
+        const bool in = tile < t1 && v < p.nvec;
+        qa[j] = in ? vt[v] : neg;
+        qb[j] = (in && has_d) ? vd[v] : neg;
+    }
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int tile = t0 + wave + kDrWaves * j;
+        if (tile < t1) {                                   // wave-uniform
+            float Mt, St, Md = kSentinel, Sd = 0.0f;
+            tile_pair<DT>(qa[j], p.c2, Mt, St, rows.tthr);
+            if (has_d) tile_pair<DT>(qb[j], p.c2, Md, Sd, rows.dthr);
+            if (lane == 0) {
+                if (leader) { tm[tile] = Mt; ts[tile] = St; dm[tile] = Md; dsum[tile] = Sd; }
+                else {
+                    dg_put(pt_x + tile, (static_cast<unsigned long long>(__float_as_uint(St)) << 32) | __float_as_uint(Mt));
+                    dg_put(pd_x + tile, (static_cast<unsigned long long>(__float_as_uint(Sd)) << 32) | __float_as_uint(Md));
+                }
+            }
+        }
+    }
+    float mt, st, md, sd;
+    if (leader) {
+        for (int tile = t1 + t; tile < p.n_tiles; tile += kDrThreads) {
+            const unsigned long long a = dg_poll(pt_x + tile, &lost);
+            const unsigned long long c = dg_poll(pd_x + tile, &lost);
+            dg_put(pt_x + tile, 0ull);
+            dg_put(pd_x + tile, 0ull);
+            tm[tile] = __uint_as_float(static_cast<uint32_t>(a));
+            ts[tile] = __uint_as_float(static_cast<uint32_t>(a >> 32));
+            dm[tile] = __uint_as_float(static_cast<uint32_t>(c));
+            dsum[tile] = __uint_as_float(static_cast<uint32_t>(c >> 32));
+        }
+        __syncthreads();
+        fold_tile_pairs(tm, ts, p.n_tiles, red, wave, lane, mt, st);
+        __syncthreads();                                   // `red` is reused
+        fold_tile_pairs(dm, dsum, p.n_tiles, red, wave, lane, md, sd);
+        if (t >= 1 && t < G) {                             // both normalisers to every partner (never all-zero: s >= 1 or m2 = sentinel)
+            unsigned long long* box = small + 3 * q.n_pad + static_cast<int64_t>(t) * 2;
+            dg_put(box, (static_cast<unsigned long long>(__float_as_uint(st)) << 32) | __float_as_uint(mt));
+            dg_put(box + 1, (static_cast<unsigned long long>(__float_as_uint(sd)) << 32) | __float_as_uint(md));
+        }
+    } else {
+        if (t < 2) {
+            bc[t] = dg_poll(mail + t, &lost);
+            dg_put(mail + t, 0ull);
+        }
+        __syncthreads();
+        if (lost) return;
+        mt = __uint_as_float(static_cast<uint32_t>(bc[0]));
+        st = __uint_as_float(static_cast<uint32_t>(bc[0] >> 32));
+        md = __uint_as_float(static_cast<uint32_t>(bc[1]));
+        sd = __uint_as_float(static_cast<uint32_t>(bc[1] >> 32));
+    }
+    const Norm2 Lt = norm2_of(mt, st), Ld = norm2_of(md, sd);
+    // ---- per tile the residual mass Z and the target mass P (the arithmetic of k_rs_mass)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        asm volatile("" : "+v"(qa[j]), "+v"(qb[j]));
+        const int tile = t0 + wave + kDrWaves * j;
+        if (tile < t1) {                                   // wave-uniform
+            float w[N], pt[N];
+            vector_weights<DT>(qa[j], qb[j], has_d, p.c2, Lt, Ld, rows.tthr, rows.dthr, w, pt);
+            float z = 0.0f, pm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { z += w[i]; pm += pt[i]; }
+            z = wave_sum(z);
+            pm = wave_sum(pm);
+            if (lane == 0) {
+                if (leader) tiles[tile] = make_float2(z, pm);
+                else dg_put(mass_x + tile, kDgValid | (static_cast<unsigned long long>(__float_as_uint(pm)) << 32) | __float_as_uint(z));   // P >= 0: its sign bit is the tag
+            }
+        }
+    }
+    if (!leader) return;
+    for (int tile = t1 + t; tile < p.n_tiles; tile += kDrThreads) {
+        const unsigned long long v = dg_poll(mass_x + tile, &lost);
+        dg_put(mass_x + tile, 0ull);
+        tiles[tile] = make_float2(__uint_as_float(static_cast<uint32_t>(v)), __uint_as_float(static_cast<uint32_t>((v & ~kDgValid) >> 32)));
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (lost) {
+        if (lane == 0) p.token[b] = -1;                    // a hand-off never arrived: poisoned, not guessed
+        return;
+    }
+    rs_pick_scan<DT>(p, b, lane, rows, tiles, Lt, Ld, sc);
 }
 
 // sequences from which the one-workgroup-per-sequence form is used (tools/rs_threshold_ab.sh, V = 152064 bf16: three launches
@@ -376,12 +495,34 @@ inline int rs_splits(int B, int n_tiles, int cus) {
 
 using namespace asd;
 
+namespace {
+int g_debug_rs_groups = 0;     // asd_debug_residual_groups (tests only): force the workgroups per sequence; 0 = heuristic, -1 = never the group form
+struct RgLayout {
+    size_t legacy_bytes, small_bytes;
+    int n_pad;
+};
+RgLayout rg_layout(int B, size_t n_tiles) {
+    RgLayout l;
+    l.legacy_bytes = round_up(static_cast<size_t>(B) * 32 * sizeof(float4), 256) + round_up(static_cast<size_t>(B) * n_tiles * sizeof(float2), 256);
+    l.n_pad = static_cast<int>(round_up(n_tiles, 32));
+    l.small_bytes = static_cast<size_t>(B) * (3 * static_cast<size_t>(l.n_pad) + kDgMaxGroups * 2) * sizeof(unsigned long long);
+    return l;
+}
+}  // namespace
+
 ASD_EXPORT size_t asd_residual_sample_workspace_bytes(int B, int V, int dtype) {
     const int esz = dtype_size(dtype);
     if (B <= 0 || V <= 0 || esz == 0) return 256;
     const size_t nvec = (static_cast<size_t>(V) * esz + 15) / 16;
-    const size_t n_tiles = (nvec + 63) / 64;
-    return round_up(static_cast<size_t>(B) * 32 * sizeof(float4), 256) + round_up(static_cast<size_t>(B) * n_tiles * sizeof(float2), 256);
+    const RgLayout l = rg_layout(B, (nvec + 63) / 64);
+    return l.legacy_bytes + round_up(l.small_bytes, 256);
+}
+
+/* tests only: force the workgroups a sequence's rows are spread over (1 ... 32; -1 = the multi-launch / one-workgroup forms;
+ * 0 = heuristic). */
+ASD_EXPORT int asd_debug_residual_groups(int groups) {
+    g_debug_rs_groups = groups;
+    return ASD_OK;
 }
 
 namespace {
@@ -415,6 +556,42 @@ int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, in
     p.token = token;
     p.d_thr = d_threshold;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // few sequences: G workgroups per sequence, rows resident in registers, one launch (the mailboxes live behind the legacy
+    // part of the workspace and must have been zeroed once: asd_workspace_init)
+    {
+        const RgLayout l = rg_layout(B, static_cast<size_t>(p.n_tiles));
+        const bool have_ws = workspace_bytes >= l.legacy_bytes + l.small_bytes && p.n_tiles <= kDrMaxTiles;
+        int G = 0;
+        if (have_ws && g_debug_rs_groups >= 0 && B <= 64) {
+            const int cus = current_device_cus();
+            G = 1;
+            while (G * 2 <= cus / B && G * 2 <= kDgMaxGroups) G *= 2;
+            while (G > 1 && (static_cast<int64_t>(B) * G > 256 || p.n_tiles / G < 8)) G >>= 1;
+            if (g_debug_rs_groups > 0 && g_debug_rs_groups <= kDgMaxGroups && static_cast<int64_t>(B) * g_debug_rs_groups <= 256) G = g_debug_rs_groups;
+            const int tpw = ((p.n_tiles + G - 1) / G + kDrWaves - 1) / kDrWaves;
+            if (tpw > 5) G = 0;
+            if (G >= 1) {
+                RgParams q{};
+                q.r = p;
+                q.G = G;
+                q.n_pad = l.n_pad;
+                q.small = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + l.legacy_bytes);
+                const dim3 grid(static_cast<unsigned>(G), static_cast<unsigned>(B)), block(kDrThreads);
+#define ASD_LAUNCH_RG(DT)                                                                                 \
+    do {                                                                                                  \
+        if (tpw <= 3) hipLaunchKernelGGL((k_residual_group<DT, 3>), grid, block, 0, st, q);               \
+        else hipLaunchKernelGGL((k_residual_group<DT, 5>), grid, block, 0, st, q);                        \
+    } while (0)
+                switch (dtype) {
+                    case ASD_DTYPE_BF16: ASD_LAUNCH_RG(ASD_DTYPE_BF16); break;
+                    case ASD_DTYPE_F16: ASD_LAUNCH_RG(ASD_DTYPE_F16); break;
+                    default: ASD_LAUNCH_RG(ASD_DTYPE_F32); break;
+                }
+#undef ASD_LAUNCH_RG
+                return launch_status();
+            }
+        }
+    }
     if (B >= kRsRowMinBatch && p.n_tiles <= kDrMaxTiles) {
         const dim3 grid(static_cast<unsigned>(B)), block(kDrThreads);
         switch (dtype) {

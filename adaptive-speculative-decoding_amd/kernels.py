@@ -480,8 +480,10 @@ class ResidualSampler:
 
     def __init__(self, B_: int, V: int, dtype: torch.dtype = torch.bfloat16, device: Optional[torch.device] = None):
         self.B, self.V, self.dtype = B_, V, dtype
+        # scratch of the multi-launch form + the mailboxes of the group form (B <= 64): zeroed ONCE, handed back empty by every call
         self.bytes = int(_lib().asd_residual_sample_workspace_bytes(B_, V, _DTYPE_CODE[dtype]))
         self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device or torch.device("cuda"))
+        B.check("asd_workspace_init", _lib().asd_workspace_init(self.buf.data_ptr(), self.bytes, _stream()))
 
     def __call__(self, t_logits: torch.Tensor, d_logits: torch.Tensor, n_acc: torch.Tensor, r: torch.Tensor,
                  bonus_logits: Optional[torch.Tensor] = None, inv_temperature: float = 1.0,

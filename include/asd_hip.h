@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define ASD_VERSION_MAJOR 0
-#define ASD_VERSION_MINOR 1
+#define ASD_VERSION_MINOR 2
 #define ASD_VERSION_PATCH 0
 
 typedef enum asd_status {
@@ -298,7 +298,10 @@ int asd_predictor_stop(const float* lp /*[B,K]*/, int64_t ld_lp, const int32_t* 
  *   token[b] = min { v : sum_{v' <= v} w(v') > r[b] * sum_v w(v) }        (inverse CDF in vocabulary order)
  * t_logits / d_logits: [B*K rows][V], bonus_logits: [B rows][V], all of `dtype`, rows ld_* ELEMENTS apart,
  * 16-byte aligned and a whole number of 16-byte vectors (ASD_ERR_ALIGNMENT otherwise).  r: [B] uniforms in [0,1).
- * workspace: >= asd_residual_sample_workspace_bytes(B, V, dtype), 256-byte aligned, no initialisation needed.
+ * workspace: >= asd_residual_sample_workspace_bytes(B, V, dtype), 256-byte aligned, zero-initialised ONCE with asd_workspace_init
+ * (since 0.2: up to 64 sequences every sequence's two rows are spread over 2 ... 32 workgroups inside ONE launch, whose single-writer /
+ * single-reader mailboxes live in the workspace and are handed back empty by every call; larger batches use the multi-launch /
+ * one-workgroup-per-sequence forms, which need no initialisation).  A hand-off that never arrives poisons the sequence (token -1).
  * ---------------------------------------------------------------------------------------- */
 size_t asd_residual_sample_workspace_bytes(int B, int V, int dtype);
 int asd_residual_sample(const void* t_logits, int64_t ld_t, const void* d_logits, int64_t ld_d,
@@ -344,6 +347,9 @@ size_t asd_draft_sample_workspace_bytes(int B, int V, int dtype);
 int asd_draft_sample(const void* logits, int64_t ld, int dtype, const float* r /*[B]*/, int B, int V,
                      float inv_temperature, float top_p, int32_t* tok /*[B] out*/, float* lp /*[B] out, may be NULL*/,
                      float* nucleus_logit /*[B] out, may be NULL*/, void* workspace, size_t workspace_bytes, void* stream);
+/* Test hook: force the workgroups per sequence of the following asd_residual_sample[_ex] calls (1 ... 32; -1 = never the group
+ * form; 0 = heuristic). */
+int asd_debug_residual_groups(int groups);
 /* Test hook (host state; no reference counterpart): force the workgroups per row of the following asd_draft_sample calls
  * (1, 2, 4 ... 32; -1 = the one-workgroup streaming form; 0 = heuristic).  Results must not depend on it. */
 int asd_debug_draft_groups(int groups);

@@ -29,7 +29,7 @@ def test_header_symbols_exported_and_bound():
 def test_version_and_status_strings():
     from asd_amd import _binding
     lib = _binding.load_library()
-    assert lib.asd_version() == 100
+    assert lib.asd_version() == 200       # 0.2.0: sampler workspaces carry mailboxes (zero-initialised once)
     assert lib.asd_status_string(0) == b"ok"
     assert b"workspace" in lib.asd_status_string(-3)
     assert lib.asd_verify_accept_workspace_bytes(32, 8, 152064, 1) % 256 == 0

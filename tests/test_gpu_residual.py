@@ -89,3 +89,88 @@ def test_rows_must_be_whole_vectors(K_):
     samp = K_.ResidualSampler(2, 1001)
     with pytest.raises(K_.B.AsdError):
         samp(t, t, torch.zeros(2, dtype=torch.int32, device="cuda"), torch.zeros(2, device="cuda"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: a sequence's two rows spread over G workgroups inside one launch (k_residual_group)
+def _residual_with_groups(K_, g, t, d, bo, n_acc, r, inv_t, thr=None):
+    import torch
+    lib = K_._lib()
+    B, V = t.shape[0], t.shape[2]
+    try:
+        lib.asd_debug_residual_groups(int(g))
+        samp = K_.ResidualSampler(B, V, t.dtype)
+        got = samp(t, d, n_acc, r, bo, inv_t, d_threshold=thr)
+        torch.cuda.synchronize()
+        return got.cpu().numpy(), samp
+    finally:
+        lib.asd_debug_residual_groups(0)
+
+
+@pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32, O.DT_F16])
+@pytest.mark.parametrize("B,K,V", [(32, 4, 152064), (8, 8, 152064), (5, 2, 40000), (64, 2, 32000)])
+def test_residual_group_kernel_matches_the_oracle_whatever_the_workgroups_per_sequence(dtype, B, K, V):
+    """asd_residual_sample_ex for few sequences: the target and the draft row of every sequence spread over 1 ... 32 workgroups
+    (forced through asd_debug_residual_groups), the multi-launch form (-1) beside them: every form picks the oracle's token
+    wherever the draw is >= 1e-5 of the mass from a CDF edge, with and without a nucleus-truncated draft row, bonus draws
+    included; the group forms agree with each other bit for bit (canonical tile pairs, fixed fold order)."""
+    import torch
+    from asd_amd import kernels as K_
+    rng = np.random.default_rng(B * 31 + K + V)
+    if dtype == O.DT_F32 and V > 100000:
+        K = min(K, 2)
+    xt = (rng.standard_normal((B * K, V)) * 3).astype(np.float32)
+    xd = (xt + rng.standard_normal((B * K, V))).astype(np.float32)
+    st, sd = encode_logits(xt, dtype), encode_logits(xd, dtype)
+    sb = encode_logits((rng.standard_normal((B, V)) * 3).astype(np.float32), dtype)
+    del xt, xd
+    n_acc = rng.integers(0, K + 1, B).astype(np.int32)
+    r = rng.uniform(0, 1, B).astype(np.float32)
+    inv_t = float(np.float32(1 / 0.7))
+    thr = O.draft_sample(sd, dtype, rng.uniform(0, 1, B * K).astype(np.float32), B * K, V, inv_t, 0.9)["thr"].reshape(B, K)
+    t = to_device_logits(st, dtype).view(B, K, V)
+    d = to_device_logits(sd, dtype).view(B, K, V)
+    bo = to_device_logits(sb, dtype).view(B, V)
+    na, rr = torch.from_numpy(n_acc).cuda(), torch.from_numpy(r).cuda()
+    for use_thr in (False, True):
+        th = torch.from_numpy(thr).cuda() if use_thr else None
+        want, margin = O.residual_sample(st, sd, dtype, n_acc, r, B, K, V, bonus=sb, inv_temperature=inv_t,
+                                         d_threshold=thr if use_thr else None)
+        ok = margin > 1e-5
+        assert ok.mean() > 0.5
+        first = None
+        for g in (-1, 1, 2, 4, 8, 16, 32):
+            if g > 0 and B * g > 256:
+                continue
+            got, samp = _residual_with_groups(K_, g, t, d, bo, na, rr, inv_t, th)
+            assert np.array_equal(got[ok], want[ok]), (g, use_thr)
+            assert int(samp.buf.count_nonzero()) == 0 or g == -1, "the group form hands its mailboxes back empty"
+            if g > 0:
+                first = got if first is None else first
+                assert np.array_equal(got, first), (g, "group forms must agree bit for bit")
+
+
+def test_residual_group_kernel_edge_rows():
+    """All drafted tokens accepted without a bonus row (token -1), an empty residual (p_t <= p_d everywhere: falls back to p_t),
+    -inf logits over whole workgroups' runs, r = 0."""
+    import torch
+    from asd_amd import kernels as K_
+    B, K, V = 6, 2, 65536
+    rng = np.random.default_rng(9)
+    xt = (rng.standard_normal((B * K, V)) * 2).astype(np.float32)
+    xd = (xt + rng.standard_normal((B * K, V)) * 0.5).astype(np.float32)
+    n_acc = np.array([0, 0, 2, 1, 0, 1], np.int32)          # sequence b draws from row b * K + n_acc[b]; sequence 2: all accepted
+    xd[2] = xt[2]                                           # sequence 1: identical rows, the residual is empty
+    xt[7, :40000] = -np.inf                                 # sequence 3: whole workgroups' runs carry no mass
+    xd[7, :40000] = -np.inf
+    r = rng.uniform(0, 1, B).astype(np.float32)
+    r[4] = 0.0
+    st, sd = encode_logits(xt, O.DT_F32), encode_logits(xd, O.DT_F32)
+    t = to_device_logits(st, O.DT_F32).view(B, K, V)
+    d = to_device_logits(sd, O.DT_F32).view(B, K, V)
+    want, margin = O.residual_sample(st, sd, O.DT_F32, n_acc, r, B, K, V)
+    for g in (0, 4, 32):
+        got, _ = _residual_with_groups(K_, g, t, d, None, torch.from_numpy(n_acc).cuda(), torch.from_numpy(r).cuda(), 1.0)
+        ok = (margin > 1e-5) & (want >= 0)
+        assert ok[[0, 3, 5]].all() and np.array_equal(got[ok], want[ok]), g
+        assert got[2] == -1 and got[3] >= 40000 and 0 <= got[1] < V
