@@ -147,7 +147,8 @@ def test_residual_group_kernel_matches_the_oracle_whatever_the_workgroups_per_se
             nvec = V * t.element_size() // 16
             legacy = -(-B * 32 * 16 // 256) * 256 + -(-B * ((nvec + 63) // 64) * 8 // 256) * 256     # scratch of the multi-launch form
             assert int(samp.buf[legacy:].count_nonzero()) == 0, "the mailboxes are handed back empty"
-            if g > 0:
+            n_tiles = (nvec + 63) // 64
+            if g > 0 and -(-(-(-n_tiles // g)) // 16) <= 5:          # the rows fit the registers of g workgroups: a group form ran
                 first = got if first is None else first
                 assert np.array_equal(got, first), (g, "group forms must agree bit for bit")
 
