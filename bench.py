@@ -16,9 +16,10 @@ default.  All modes execute exactly the same kernels on the same buffers and tim
 steps.
 
 A step = ONE pass of the hot path over one batch of synthetic target logits already resident in
-HBM:  asd_verify_accept (gather + log-sum-exp + acceptance test over [B,K,V] bf16)  followed by
-asd_predictor_stop (log-prob statistics -> 64-d features -> 64x32x1 predictor -> Bayes -> DP stop
-rule).  Logits buffers rotate through > 600 MB so the figure is HBM, not Infinity Cache.
+HBM, as ONE launch:  asd_verify_accept_fused_ex = gather + log-sum-exp + acceptance test over [B,K,V] bf16, and -- inside
+the same kernel, by the wave that completes each sequence -- log-prob statistics -> 64-d features -> 64x32x1 predictor ->
+Bayes -> DP stop rule.  (`--two-launch`: asd_verify_accept_ex followed by asd_predictor_stop, the step of rounds 1-2.)
+Logits buffers rotate through > 600 MB so the figure is HBM, not Infinity Cache.
 Prints ONE JSON line (rank 0; file descriptor 1 is pointed at stderr for everything else, RCCL's warnings included).
 `value` = verified tokens / s = sum_b (n_acc[b] + 1) per second, whole job.  N > 1: one process per GPU, every rank
 verifies its own batch of the same shape (batch-parallel replicas, no data-path collective; "weak" scaling); the barriers
@@ -26,7 +27,8 @@ and the max-over-ranks of the times run over gloo, RCCL carries the one exchange
 Before the W warm-up steps the same step runs untimed for ~120 ms (a fresh box needs that to leave its idle clocks; the
 driver's job is 20 steps), and up to 64 steps are captured per graph (a short job is one replay).
 
-roofline: the verify kernel's ALGORITHMIC bytes (B*K*V*2 + 17*B*K + 4*B, +8*B for
+roofline: the PLAIN verify kernel's (k_verify<..., FUSED = false>: the batched verify + accept kernel the north star names;
+`roofline.step_kernel` repeats the measurement for the FUSED instantiation the default step launches) ALGORITHMIC bytes (B*K*V*2 + 17*B*K + 4*B, +8*B for
 the ballot word) divided by its mean launch duration.  Duration = HIP events recorded on the launch
 stream around a back-to-back run of the verify kernel alone over the same rotating buffers, taken
 right after the timed region in the same process (it includes the inter-kernel gap, so it is a
