@@ -23,29 +23,30 @@
 // count is K-1 holds the complete mask: it writes n_acc / accept_bits and zeroes the word.  No
 // payload store, no drain, no read-back on the tail.
 //
-// Split rows (S > 1; few rows, many CUs).
-// Hand-off.  The slice result is published as ONE self-tagging 8-byte granule (write-through, agent scope; never
-// all-zero, an empty slot is) and the publishing lane takes a ticket on the sequence's counter WITHOUT draining the
-// store (the drain was a store-ack round trip on every slice's tail).  The workgroup whose ticket is the last of the
-// sequence's K*S tickets stages the K*S granules of the K candidate rows in LDS -- it re-reads a slot that is still
-// empty: every store it waits for was ISSUED before the ticket add that made it the finisher, so the wait is one store
-// latency; the loop is bounded (2^20 polls), and a slot that never fills POISONS its row (lp_t = NaN, rejected; the
-// in-kernel epilogue then reports score = NaN, k* = L - 1, stop = 0) instead of folding a zero -- hands every slot back
-// empty, combines the S slices of every row in slice order (=> bitwise deterministic, independent of arrival order),
-// gathers the drafted token's logit, runs the acceptance test, and turns the K accept flags into the sequence's accept
-// mask / accepted-prefix length with one wave ballot.  With the in-kernel epilogue (FUSED) the same wave, which now
-// holds all K lp_t in its lanes, runs the predictor / stop rule on the spot: no hand-off of its own.
-// Workspace invariant: ticket words, ballot words, lp slots and granule slots are ZERO between calls (asd_workspace_init
-// once; every call hands back what it used), whatever B / K / S the calls had -- so calls of different shapes may share
-// one workspace in stream order.  Granule regions are per sequence and padded to whole 256-byte blocks, so every line of
-// them has exactly one reader per launch.  Every sequence's ticket / ballot word sits in its own 128-byte line: atomics
-// on one line serialise at the memory side (measured: 32 tickets packed in one line made 4096 arrivals cost 80 us).
-// hipGraph-replay safe: no epoch argument, no memset node.
+// Hand-off between workgroups (round 3).  Every word that crosses workgroups has ONE writer and ONE reader and tags itself:
+// once published it is never all-zero (a granule's s is > 0 or its m2 is the sentinel; slots carry a tag bit), an empty
+// word is.  It is stored write-through (agent scope) and NOT drained; the reader re-reads a word that is still empty --
+// bounded, 2^20 polls -- and stores zero back.  A word that never arrives POISONS what depended on it (lp_t = NaN and
+// reject for the row; score = NaN, k* = L - 1, stop = 0 for the sequence's epilogue), it is never folded as a zero.
+// Who reads is decided by POSITION: a sequence's designated finisher is its LAST workgroup in dispatch order (last row;
+// with split rows: last row, last slice); its siblings were dispatched before it and wait for nothing.  No ticket, no epoch
+// argument, no memset node: the workspace is all-zero between calls whatever B / K / S they had, so calls of different
+// shapes may share one workspace in stream order, and launches replay from a hipGraph.
 //
-// In-kernel epilogue on the one-workgroup-per-row path: every row hands its lp_t to the sequence's finisher as a
-// self-tagging 8-byte slot (1 << 32 | bits of lp_t) in lines 1-2 of the sequence's workspace block, again without a
-// drain; the arrival that completes the ballot polls the K slots (bounded, poisoning as above), zeroes them, and its
-// whole wave runs epi_finish.
+// Split rows (S > 1; few rows, many CUs).  Each slice publishes ONE 8-byte granule {m2, s}; slice 0 of a row, which
+// fetched the token id and then the token's logit under its stream, also publishes that logit in the row's slot.  The
+// finisher stages the K*S granules in LDS, combines the S slices of every row in slice order (=> bitwise deterministic,
+// independent of arrival order), runs the K acceptance tests on K lanes and turns the flags into the accept mask /
+// accepted-prefix length with one wave ballot.  With the in-kernel epilogue (FUSED) the same wave, which now holds all K
+// lp_t in its lanes, runs the predictor / stop rule on the spot.  (Round 2: a ticket per slice, then the last arriver
+// loaded tok and then the logit -- three dependent memory round trips behind the last slice.)
+// Granule regions are per sequence and padded to whole 256-byte blocks; every sequence's block starts on its own
+// 128-byte line (32 tickets packed in one line made 4096 arrivals cost 80 us -- measured in round 1).
+//
+// In-kernel epilogue on the one-workgroup-per-row path (FUSED): no ballot atomic -- every row stores
+// (1 << 63 | flag << 32 | bits of lp_t) into its slot; the designated finisher issues its feature / p_hist / cost loads,
+// polls the K - 1 slots, zeroes them, forms the mask with a wave ballot and its whole wave runs epi_finish_lds (the
+// predictor's weights were put into LDS by DMA under the stream; the log-prob statistics come from registers).
 //
 // Reference arithmetic this replaces: src/training/generate_training_data.py:128-136
 // (softmax -> index -> log -> .item(), one token per iteration).  The acceptance test has no
