@@ -112,8 +112,66 @@ static __device__ void wave_logprob_stats_t(double* vals, double* sorted, double
     }
 }
 
-static __device__ void wave_logprob_stats(double* vals, double* sorted, double* sq, int n, int lane, double (&out)[5]) {
+[[maybe_unused]] static __device__ void wave_logprob_stats(double* vals, double* sorted, double* sq, int n, int lane, double (&out)[5]) {
     wave_logprob_stats_t<false>(vals, sorted, sq, n, lane, out);
+}
+
+// ---- the five statistics again, for n <= 64 values held ONE PER LANE (the in-kernel epilogue: n = K), without LDS: every
+// value is fetched with v_readlane (the lane index is wave-uniform), every lane computes the same sums.  Operation for
+// operation the arithmetic of wave_logprob_stats (numpy's pairwise leaf routine, population std, linear-interpolated
+// percentile, median), so the results are bit-identical; what goes away is seven LDS round trips and three wave barriers on
+// the tail of the verify kernel (~0.4 us of its 2.5 us epilogue).
+__device__ __forceinline__ double lane_value(double v, int j) {      // j wave-uniform
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(b), j);
+    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(b >> 32), j);
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+__device__ __forceinline__ double np_sum_leaf_lanes(double v, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res = res + lane_value(v, i);
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = lane_value(v, j);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = r[j] + lane_value(v, i + j);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + lane_value(v, i);
+    return res;
+}
+// v: this lane's value (lanes < n); out: the same five numbers in EVERY lane
+__device__ __forceinline__ void wave_logprob_stats_lanes(double v, int n, int lane, double (&out)[5]) {
+    if (n <= 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) out[i] = 0.0;
+        return;
+    }
+    const double mean = np_sum_leaf_lanes(v, n) / static_cast<double>(n);
+    const double t = v - mean;
+    const double var = np_sum_leaf_lanes(t * t, n) / static_cast<double>(n);
+    int rank = 0;                                                    // stable rank of this lane's value
+    for (int j = 0; j < n; ++j) {
+        const double w = lane_value(v, j);
+        rank += (w < v) || (w == v && j < lane);
+    }
+    auto sorted_at = [&](int r) -> double {                          // r wave-uniform, 0 <= r < n
+        const unsigned long long m = __ballot(lane < n && rank == r);
+        return lane_value(v, static_cast<int>(__builtin_ctzll(m)));
+    };
+    const double vi = static_cast<double>(n - 1) * 0.25;
+    const int lo = static_cast<int>(floor(vi));
+    const int hi = lo + 1 < n ? lo + 1 : n - 1;
+    out[0] = mean;
+    out[1] = sqrt(var);
+    out[2] = sorted_at(0);
+    out[3] = np_lerp(sorted_at(lo), sorted_at(hi), vi - static_cast<double>(lo));
+    out[4] = (n & 1) ? sorted_at(n / 2) : (sorted_at(n / 2 - 1) + sorted_at(n / 2)) / 2.0;
 }
 
 // ---- fused epilogue: parameters and the lane-0 decision tail -----------------------------
@@ -242,14 +300,8 @@ __device__ __forceinline__ void epi_finish(const FusedParams& p, int b, int lane
                                            const EpiPrefetch& e, double* dvals, float* xs) {
     float xv = e.xv;
     if (want_stats) {
-        double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if (lane < n) dvals[lane] = static_cast<double>(lpv);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        wave_logprob_stats(dvals, dvals + 64, dvals + 128, n, lane, st);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) st[i] = bcast_lane0(st[i]);
+        double st[5];
+        wave_logprob_stats_lanes(static_cast<double>(lpv), n, lane, st);      // n <= 64 values, one per lane: registers + readlane only
         if (p.stats && lane == 0) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
@@ -274,64 +326,6 @@ __device__ __forceinline__ void epi_finish(const FusedParams& p, int b, int lane
     if (lane == 0) decide_and_store_impl<true>(p, b, sc, e.d);
 }
 
-
-// ---- the five statistics again, for n <= 64 values held ONE PER LANE (the in-kernel epilogue: n = K), without LDS: every
-// value is fetched with v_readlane (the lane index is wave-uniform), every lane computes the same sums.  Operation for
-// operation the arithmetic of wave_logprob_stats (numpy's pairwise leaf routine, population std, linear-interpolated
-// percentile, median), so the results are bit-identical; what goes away is seven LDS round trips and three wave barriers on
-// the tail of the verify kernel (~0.4 us of its 2.5 us epilogue).
-__device__ __forceinline__ double lane_value(double v, int j) {      // j wave-uniform
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(b), j);
-    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(b >> 32), j);
-    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
-}
-__device__ __forceinline__ double np_sum_leaf_lanes(double v, int n) {
-    if (n < 8) {
-        double res = 0.0;
-        for (int i = 0; i < n; ++i) res = res + lane_value(v, i);
-        return res;
-    }
-    double r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = lane_value(v, j);
-    int i = 8;
-    for (; i < n - (n % 8); i += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = r[j] + lane_value(v, i + j);
-    }
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res = res + lane_value(v, i);
-    return res;
-}
-// v: this lane's value (lanes < n); out: the same five numbers in EVERY lane
-__device__ __forceinline__ void wave_logprob_stats_lanes(double v, int n, int lane, double (&out)[5]) {
-    if (n <= 0) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) out[i] = 0.0;
-        return;
-    }
-    const double mean = np_sum_leaf_lanes(v, n) / static_cast<double>(n);
-    const double t = v - mean;
-    const double var = np_sum_leaf_lanes(t * t, n) / static_cast<double>(n);
-    int rank = 0;                                                    // stable rank of this lane's value
-    for (int j = 0; j < n; ++j) {
-        const double w = lane_value(v, j);
-        rank += (w < v) || (w == v && j < lane);
-    }
-    auto sorted_at = [&](int r) -> double {                          // r wave-uniform, 0 <= r < n
-        const unsigned long long m = __ballot(lane < n && rank == r);
-        return lane_value(v, static_cast<int>(__builtin_ctzll(m)));
-    };
-    const double vi = static_cast<double>(n - 1) * 0.25;
-    const int lo = static_cast<int>(floor(vi));
-    const int hi = lo + 1 < n ? lo + 1 : n - 1;
-    out[0] = mean;
-    out[1] = sqrt(var);
-    out[2] = sorted_at(0);
-    out[3] = np_lerp(sorted_at(lo), sorted_at(hi), vi - static_cast<double>(lo));
-    out[4] = (n & 1) ? sorted_at(n / 2) : (sorted_at(n / 2 - 1) + sorted_at(n / 2)) / 2.0;
-}
 
 // ---- the same epilogue for a kernel that cannot afford the weights in registers while it streams (k_verify<FUSED>:
 // 55 more VGPRs took it to 135 and to ONE workgroup per CU).  The packed weights sit in LDS (put there by LDS-DMA at the
