@@ -58,6 +58,17 @@ SIGNATURES = {
                                    _vp, _sz, _vp]),
     "asd_lm_head_packed_bytes": (_sz, [_i, _i]),
     "asd_lm_head_pack_weights": (_i, [_vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    "asd_linear_workspace_bytes": (_sz, [_i, _i, _i]),
+    "asd_linear": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
+    "asd_linear_ex": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
+    "asd_debug_linear_slices": (_i, [_i, _i, _i]),
+    "asd_rmsnorm": (_i, [_vp, _i64, _vp, _f, _i, _i, _i, _vp, _i64, _vp]),
+    "asd_rope_kv_store": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "asd_attn_ragged": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "asd_silu_mul": (_i, [_vp, _i64, _i, _i, _i, _vp, _i64, _vp]),
+    "asd_decoder_scratch_bytes": (_sz, [_vp, _i]),
+    "asd_decoder_forward": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "asd_debug_force_linear_slices": (_i, [_i]),
     "asd_lm_head_partial": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
     "asd_commit_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),
     "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
@@ -84,6 +95,18 @@ class VerifyOptions(C.Structure):
 def verify_options(inv_temperature: float = 1.0, splits: int = 0, threads: int = 0, unroll: int = 0,
                    nontemporal: int = -1) -> VerifyOptions:
     return VerifyOptions(float(inv_temperature), int(splits), int(threads), int(unroll), int(nontemporal))
+
+
+class Layer(C.Structure):
+    """asd_layer_t"""
+    _fields_ = [("ln1_w", _vp), ("qkv_w", _vp), ("qkv_b", _vp), ("o_w", _vp), ("ln2_w", _vp), ("gate_up_w", _vp), ("down_w", _vp),
+                ("k_cache", _vp), ("vt_cache", _vp)]
+
+
+class DecoderShape(C.Structure):
+    """asd_decoder_shape_t"""
+    _fields_ = [("hidden", _i), ("heads", _i), ("kv_heads", _i), ("head_dim", _i), ("intermediate", _i), ("rms_eps", _f),
+                ("inv_freq", _vp), ("t_max", _i)]
 
 
 class AsdError(RuntimeError):

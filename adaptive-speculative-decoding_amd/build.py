@@ -29,6 +29,7 @@ SOURCES = {
     "verify_accept.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=11"],
     "residual_sample.hip": [],
     "draft_sample.hip": [],
+    "decoder.hip": [],
     "commit.hip": [],
     "lm_head_verify.hip": ["-ffp-contract=off"],  # ends in the same finish_row arithmetic as verify_accept.hip
     "decision.hip": ["-ffp-contract=off"],

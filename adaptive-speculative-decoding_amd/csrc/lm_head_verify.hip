@@ -80,8 +80,107 @@ struct LmHeadParams {
     int need_argmax;     // the caller wants the row arg-max (argmax_out / greedy): otherwise the epilogue skips its bookkeeping
     int k_slices;        // > 1: every column block is cut into this many reduction slices (one workgroup each)
     float* slabs;        // [n_blocks][k_slices][8 waves][2 * NTW * 4][64 lanes] float4: partial accumulators
-    uint32_t* tickets;   // [n_blocks], zero before the launch; the slice that draws k_slices - 1 finishes the block
+    uint32_t* tickets;   // [n_blocks], zero before the launch; the slice that draws k_slices - 1 finishes the block (and zeroes it)
+    // STORE kernels (asd_linear: the same products written out as a [M][N] matrix instead of folded into log-sum-exp records)
+    void* out;           // [M][ld_out], element type of the operands
+    int64_t ld_out;
+    const void* bias;    // [V] (the N of the linear layer), element type of the operands, or NULL
+    const void* residual;   // [M][ld_res] added to the product (may alias out: every element is read, then written, by one lane), or NULL
+    int64_t ld_res;
 };
+
+// ---- STORE epilogue: lane (r, h) holds, per 32 x 32 accumulator tile, 4 x 4 consecutive output columns
+// n_first + 8 q .. + 3 (q = 0..3) of ONE row m: four 8-byte stores (the two half-waves' pieces of a row are adjacent, the
+// four q of a tile make a 64-byte run; L2 merges them).  One rounding f32 -> bf16 / f16 (RNE) at the store; bias added in f32.
+template <bool F16>
+__device__ __forceinline__ uint32_t pack_pair(float a, float b) {
+    if constexpr (F16) {
+        const _Float16 x = static_cast<_Float16>(a), y = static_cast<_Float16>(b);
+        return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, x)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, y)) << 16);
+    } else {
+        const __bf16 x = static_cast<__bf16>(a), y = static_cast<__bf16>(b);
+        return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, x)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, y)) << 16);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ float unpack_elem(uint32_t w, int hi) {
+    const uint16_t u = static_cast<uint16_t>(hi ? (w >> 16) : (w & 0xffffu));
+    if constexpr (F16) return static_cast<float>(__builtin_bit_cast(_Float16, u));
+    else return __uint_as_float(static_cast<uint32_t>(u) << 16);
+}
+template <bool F16>
+__device__ __forceinline__ void store_tile16(const f32x16& a, int m, int n_first, int slice, const LmHeadParams& p) {
+    if (m >= p.M) return;
+    if (p.k_slices > 1) {
+        // a reduction slice: f32 partials into this slice's [M][V] slab; k_linear_reduce adds the slabs in slice order
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        float* const row = p.slabs + (static_cast<int64_t>(slice) * p.M + m) * p.V;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n_first + 8 * q;
+            if (n >= p.V) continue;
+            f32x4 v;
+            v[0] = a[4 * q]; v[1] = a[4 * q + 1]; v[2] = a[4 * q + 2]; v[3] = a[4 * q + 3];
+            *reinterpret_cast<f32x4*>(row + n) = v;
+        }
+        return;
+    }
+    char* const row = static_cast<char*>(p.out) + static_cast<int64_t>(m) * p.ld_out * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = n_first + 8 * q;
+        if (n >= p.V) continue;                      // N % 4 == 0 (checked by the launcher): a piece is all in or all out
+        float v0 = a[4 * q], v1 = a[4 * q + 1], v2 = a[4 * q + 2], v3 = a[4 * q + 3];
+        if (p.bias) {
+            const uint2 bw = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.bias) + static_cast<int64_t>(n) * 2);
+            v0 += unpack_elem<F16>(bw.x, 0); v1 += unpack_elem<F16>(bw.x, 1);
+            v2 += unpack_elem<F16>(bw.y, 0); v3 += unpack_elem<F16>(bw.y, 1);
+        }
+        if (p.residual) {
+            const uint2 rw = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.residual) +
+                                                             (static_cast<int64_t>(m) * p.ld_res + n) * 2);
+            v0 += unpack_elem<F16>(rw.x, 0); v1 += unpack_elem<F16>(rw.x, 1);
+            v2 += unpack_elem<F16>(rw.y, 0); v3 += unpack_elem<F16>(rw.y, 1);
+        }
+        uint2 o;
+        o.x = pack_pair<F16>(v0, v1);
+        o.y = pack_pair<F16>(v2, v3);
+        *reinterpret_cast<uint2*>(row + static_cast<int64_t>(n) * 2) = o;
+    }
+}
+
+// the slabs of a sliced STORE launch -> out: thread = 4 consecutive columns of one row; slices added in slice order
+template <bool F16>
+__global__ __launch_bounds__(256) void k_linear_reduce(const float* __restrict__ slabs, int k_slices, int M, int N,
+                                                       const void* __restrict__ bias, const void* residual, int64_t ld_res,
+                                                       void* out, int64_t ld_out) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int n4 = N / 4;
+    if (i >= static_cast<int64_t>(M) * n4) return;
+    const int m = static_cast<int>(i / n4), n = static_cast<int>(i % n4) * 4;
+    const float* src = slabs + static_cast<int64_t>(m) * N + n;
+    const int64_t stride = static_cast<int64_t>(M) * N;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+    for (int sl = 1; sl < k_slices; ++sl) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + sl * stride);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    if (bias) {
+        const uint2 bw = *reinterpret_cast<const uint2*>(static_cast<const char*>(bias) + static_cast<int64_t>(n) * 2);
+        acc[0] += unpack_elem<F16>(bw.x, 0); acc[1] += unpack_elem<F16>(bw.x, 1);
+        acc[2] += unpack_elem<F16>(bw.y, 0); acc[3] += unpack_elem<F16>(bw.y, 1);
+    }
+    if (residual) {
+        const uint2 rw = *reinterpret_cast<const uint2*>(static_cast<const char*>(residual) + (static_cast<int64_t>(m) * ld_res + n) * 2);
+        acc[0] += unpack_elem<F16>(rw.x, 0); acc[1] += unpack_elem<F16>(rw.x, 1);
+        acc[2] += unpack_elem<F16>(rw.y, 0); acc[3] += unpack_elem<F16>(rw.y, 1);
+    }
+    uint2 o;
+    o.x = pack_pair<F16>(acc[0], acc[1]);
+    o.y = pack_pair<F16>(acc[2], acc[3]);
+    *reinterpret_cast<uint2*>(static_cast<char*>(out) + (static_cast<int64_t>(m) * ld_out + n) * 2) = o;
+}
 
 template <int PENDING>
 __device__ __forceinline__ void wait_and_meet() {
@@ -121,19 +220,23 @@ __device__ __forceinline__ void fold_tile16(const f32x16& a, int n_first, int tk
 // NTW: 32-column accumulator tiles per wave: 4 (256-column block) or 2 (128-column block).
 // HPASSES: 64-row DMA passes over the hidden rows, ceil(rows / 64) for a call with M <= 256 rows (1, 2 or 4):
 // at M = 64 three quarters of the hidden-state traffic into LDS would be padding.
-template <int NTW, int HPASSES, bool F16>
-__global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
-    constexpr int BN = 64 * NTW;             // 2 wave columns
+// WM: wave rows (4: the lm_head form, 4 x 2 waves over 256 rows; STORE launches also run 2 x 4 waves over a row block of
+// <= 128 rows and 1 x 8 waves over one of <= 64 rows, so that a short LAST row block -- M = 288 = 256 + 32, the K + 1 = 9
+// positions of 32 sequences -- costs its share of MFMAs instead of a full block's).  A wave always owns 64 rows x 32 * NTW
+// columns; the block is 32 * NTW * (8 / WM) columns wide.
+template <int NTW, int HPASSES, bool F16, bool STORE, int WM>
+__device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* const lds) {
+    constexpr int WN = 8 / WM;               // wave columns
+    constexpr int BN = 32 * NTW * WN;
     constexpr int kWSlot = BN * 128;         // one weight superstage
     constexpr int kHSlot = kBM * 128;        // one hidden superstage
     constexpr int WPASSES = BN / 64;         // DMA instructions per thread and superstage (64 rows per pass)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[kWRing * kWSlot + kHRing * kHSlot];
     unsigned char* const lds_h = lds + kWRing * kWSlot;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wv = t >> 6;
-    const int wm = wv & 3;     // wave row: hidden rows 64 * wm ..
-    const int wn = wv >> 2;    // wave column: weight rows 32 * NTW * wn ..
+    const int wm = wv % WM;    // wave row: hidden rows 64 * wm ..
+    const int wn = wv / WM;    // wave column: weight rows 32 * NTW * wn ..
     const int r = lane & 31;
     const int h = lane >> 5;
     // M > 256: the row blocks that share a weight tile get ids 8 apart, i.e. the same XCD (workgroups are
@@ -193,9 +296,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     }
     // this workgroup's superstages [s_begin, n_super): all of them, or its reduction slice
     const int total_super = p.D / kSuper;
-    const int per_slice = (total_super + p.k_slices - 1) / p.k_slices;
-    const int s_begin = p.k_slices > 1 ? min(slice * per_slice, total_super) : 0;
-    const int n_super = p.k_slices > 1 ? min(s_begin + per_slice, total_super) : total_super;
+    const int s_begin = static_cast<int>(static_cast<int64_t>(slice) * total_super / p.k_slices);        // balanced: no empty slice
+    const int n_super = static_cast<int>(static_cast<int64_t>(slice + 1) * total_super / p.k_slices);
     auto issue_w = [&](int stage) {
         const char* src = wbase + static_cast<int64_t>(stage) * w_stage_stride;
         asm volatile("" : "+s"(src));   // keep the base in SGPRs: without it LLVM folds the lane offset into a 64-bit VGPR pointer
@@ -350,10 +452,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     // ticket adds the others' and goes on to the epilogue.  Hand-off: plain 16-byte stores, every wave drains
     // them (vmcnt), workgroup barrier, ONE agent-scope release + ticket by lane 0; the finisher acquires once,
     // barrier, then plain loads.  The ticket word is zeroed by the launcher before every call.
-    if (p.k_slices > 1) {
+    if (!STORE && p.k_slices > 1) {      // (a sliced STORE launch writes its partials as [slice][M][N] slabs: store_tile16)
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         constexpr int kChunks = 2 * NTW * 4;                       // float4 chunks per lane
-        const int64_t block_slabs = static_cast<int64_t>(nb) * p.k_slices;
+        const int unit = nb * p.m_blocks + mb;                     // (column block, row block): one ticket, k_slices slabs
+        const int64_t block_slabs = static_cast<int64_t>(unit) * p.k_slices;
         auto slab = [&](int sl) {
             return reinterpret_cast<f32x4*>(p.slabs) + ((block_slabs + sl) * 8 + wv) * (kChunks * 64) + lane;
         };
@@ -377,9 +480,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
         if (t == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t old = __hip_atomic_fetch_add(p.tickets + nb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t old = __hip_atomic_fetch_add(p.tickets + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool last = old == static_cast<uint32_t>(p.k_slices - 1);
             if (last) {
+                __hip_atomic_store(p.tickets + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every slice has drawn: zero for the next call
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -414,6 +518,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     // the two wave columns meet in LDS (free now: every DMA was retired by the last wait), and the block
     // writes ONE record per row: (m2, s, g) and the block's arg-max (value, vocabulary id; ties -> lowest id,
     // NaN logits never win).
+    if constexpr (STORE) {
+        if (wave_works) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    store_tile16<F16>(acc[mt][nt], m0 + 64 * wm + 32 * mt + r, n0 + 32 * NTW * wn + 32 * nt + 4 * h, slice, p);
+        }
+        return;
+    }
     float* const meet = reinterpret_cast<float*>(lds);   // [256 rows][kMsg]
     __syncthreads();                                      // the last superstage's fragment reads are done
     float tm2[2], ts[2], tg[2], tbv[2];
@@ -471,6 +585,28 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
     }
 }
 
+template <int NTW, int HPASSES, bool F16>
+__global__ __launch_bounds__(kThreads, 1) void k_lm_head_tile(LmHeadParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[kWRing * 64 * NTW * 128 + kHRing * kBM * 128];
+    tile_body<NTW, HPASSES, F16, false, 4>(p, lds);
+}
+
+// asd_linear, M > 64: every row block of 256 rows in the 4 x 2 form, a last row block of <= 128 / <= 64 rows in the 2 x 4 /
+// 1 x 8 form -- in ONE launch, so that the row blocks of a weight tile still share it through the XCD's L2
+template <bool F16>
+__global__ __launch_bounds__(kThreads, 1) void k_linear_tile(LmHeadParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[kWRing * 256 * 128 + kHRing * kBM * 128];
+    // (the row block of this workgroup, as tile_body decodes it)
+    int id = static_cast<int>(blockIdx.x) / p.k_slices;
+    const int group = 8 * p.m_blocks;
+    const int swizzled = (p.n_blocks / 8) * group;
+    const int mb = id < swizzled ? (id % group) / 8 : (id - swizzled) % p.m_blocks;
+    const int rows_h = min(kBM, p.M - mb * kBM);
+    if (rows_h > 128) tile_body<4, 4, F16, true, 4>(p, lds);
+    else if (rows_h > 64) tile_body<2, 2, F16, true, 2>(p, lds);
+    else tile_body<1, 1, F16, true, 1>(p, lds);
+}
+
 // ---- M > 256 rows (several row blocks share every weight tile): FOUR waves per workgroup, 128 x 128 logits per wave.
 // With the weights re-read from L2 by the row blocks of a tile the call is MFMA-bound, and the 8-wave kernel above spends
 // its issue slots on fragment reads: 6 ds_read_b128 per 8 MFMAs and wave, two waves per SIMD taking turns, 0.94-0.97 PF.
@@ -492,8 +628,8 @@ constexpr int kQSlot = kBM * 128;             // one operand, one superstage: 25
 //   1 x 4 waves, 2 x 2 tiles   ...                       <= 64 rows           (a quarter)
 // The partial forms live in the SAME launch as the full ones: the row blocks of a weight tile run side by side on one XCD
 // and share the tile through its L2 -- a separate launch for the last row block would stream the weights from HBM again.
-template <int WM, int MT, int NT, bool F16>
-__device__ __forceinline__ void quad_tile(const LmHeadParams& p, int mb, int nb, unsigned char* lds) {
+template <int WM, int MT, int NT, bool F16, bool STORE>
+__device__ __forceinline__ void quad_tile(const LmHeadParams& p, int mb, int nb, int slice, unsigned char* lds) {
     constexpr int kSlot = kQSlot;
     constexpr int WN = 4 / WM;
     static_assert(WM * MT * 32 <= kBM && WN * NT * 32 == 256, "tile shape");
@@ -521,10 +657,13 @@ __device__ __forceinline__ void quad_tile(const LmHeadParams& p, int mb, int nb,
     }
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
     u32x4v sw[8], sh[8];
-    const int n_super = p.D / kSuper;
+    // this workgroup's superstages: all of them, or (sliced STORE launches) its balanced share; S below counts from s_first
+    const int total_super = p.D / kSuper;
+    const int s_first = static_cast<int>(static_cast<int64_t>(slice) * total_super / p.k_slices);
+    const int n_super = static_cast<int>(static_cast<int64_t>(slice + 1) * total_super / p.k_slices) - s_first;
     auto load_piece = [&](int S, int ps) {
-        sw[ps] = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(wbase + static_cast<int64_t>(S) * w_stage_stride + woff[ps]));
-        sh[ps] = *reinterpret_cast<const u32x4v*>(hbase + static_cast<int64_t>(S) * (kSuper * 2) + hoff[ps]);
+        sw[ps] = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(wbase + static_cast<int64_t>(s_first + S) * w_stage_stride + woff[ps]));
+        sh[ps] = *reinterpret_cast<const u32x4v*>(hbase + static_cast<int64_t>(s_first + S) * (kSuper * 2) + hoff[ps]);
     };
     auto store_piece = [&](int buf, int ps) {
         unsigned char* wb = lds + buf * 2 * kSlot;
@@ -634,6 +773,16 @@ __device__ __forceinline__ void quad_tile(const LmHeadParams& p, int mb, int nb,
     // ---- epilogue (as k_lm_head_tile): D[vocab row][m column]; lane (r, h) holds row m of four 32-row tiles and, per
     // 32-column tile, the vocabulary ids n = tile + (i & 3) + 8 * (i >> 2) + 4 * h.  A wave folds its 128 columns per row,
     // the two wave columns meet in LDS, the block writes ONE record per row.
+    if constexpr (STORE) {
+        if (wave_works) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    store_tile16<F16>(acc[mt][nt], m0 + 32 * MT * wm + 32 * mt + r, n0 + 32 * NT * wn + 32 * nt + 4 * h, slice, p);
+        }
+        return;
+    }
     float* const meet = reinterpret_cast<float*>(lds);   // [WN - 1 wave columns][256 rows][kMsg]; every fragment read was waited for
     float tm2[MT], ts[MT], tg[MT], tbv[MT];
     int tbi[MT];
@@ -694,12 +843,16 @@ __device__ __forceinline__ void quad_tile(const LmHeadParams& p, int mb, int nb,
     }
 }
 
-template <bool F16>
+template <bool F16, bool STORE = false>
 __global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * kQSlot];    // [buffer][weights | hidden]
-    int mb, nb;
+    int mb, nb, slice = 0;
     {   // the row blocks that share a weight tile get ids 8 apart: one XCD, one dispatch round (see k_lm_head_tile)
-        const int id = static_cast<int>(blockIdx.x);
+        int id = static_cast<int>(blockIdx.x);
+        if (p.k_slices > 1) {           // (STORE launches only) the slices of a tile are neighbours
+            slice = id % p.k_slices;
+            id /= p.k_slices;
+        }
         const int group = 8 * p.m_blocks;
         const int swizzled = (p.n_blocks / 8) * group;
         if (id < swizzled) {
@@ -712,9 +865,9 @@ __global__ __launch_bounds__(kQThreads, 1) void k_lm_head_quad(LmHeadParams p) {
         }
     }
     const int rows_h = min(kBM, p.M - mb * kBM);       // block-uniform: only the last row block can be partial
-    if (rows_h > 128) quad_tile<2, 4, 4, F16>(p, mb, nb, lds);
-    else if (rows_h > 64) quad_tile<1, 4, 2, F16>(p, mb, nb, lds);
-    else quad_tile<1, 2, 2, F16>(p, mb, nb, lds);
+    if (rows_h > 128) quad_tile<2, 4, 4, F16, STORE>(p, mb, nb, slice, lds);
+    else if (rows_h > 64) quad_tile<1, 4, 2, F16, STORE>(p, mb, nb, slice, lds);
+    else quad_tile<1, 2, 2, F16, STORE>(p, mb, nb, slice, lds);
 }
 
 // ---- M <= 64 rows (B*K <= 64: BASELINE configs[1], batch 8 x draft_len 8): the call is HBM-bound (64 flop per weight byte),
@@ -727,7 +880,7 @@ constexpr int kSkWRing = 4;
 constexpr int kSkHRing = 3;
 constexpr int kSkRows = 64;
 
-template <bool F16>
+template <bool F16, bool STORE = false>
 __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) {
     constexpr int BN = 256;
     constexpr int kWSlot = BN * 128;
@@ -740,7 +893,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) 
     const int wv = t >> 6;          // wave column: vocabulary rows 32 * wv .. of the block
     const int r = lane & 31;
     const int h = lane >> 5;
-    const int nb = static_cast<int>(blockIdx.x);
+    // reduction slices (STORE launches of narrow matrices: 14 column blocks cannot feed 256 CUs): the slices of a block are
+    // neighbours in the grid, slice i owns the superstages [i * total / k, (i + 1) * total / k)
+    const int nb = static_cast<int>(blockIdx.x) / p.k_slices;
+    const int slice = static_cast<int>(blockIdx.x) % p.k_slices;
     const int n0 = p.col0 + nb * BN;
     const int rows_w = min(BN, p.V - n0);
     const int rows_h = min(kSkRows, p.M);
@@ -764,7 +920,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) 
         const int seg = (lane & 7) ^ ((drow >> 1) & 7);
         hoff = static_cast<uint32_t>(min(drow, rows_h - 1)) * static_cast<uint32_t>(p.ld_h * 2) + seg * 16;
     }
-    const int n_super = p.D / kSuper;
+    const int total_super = p.D / kSuper;
+    const int s_begin = static_cast<int>(static_cast<int64_t>(slice) * total_super / p.k_slices);
+    const int n_super = static_cast<int>(static_cast<int64_t>(slice + 1) * total_super / p.k_slices);
     auto issue_w = [&](int stage) {
         const char* src = wbase + static_cast<int64_t>(stage) * w_stage_stride;
         asm volatile("" : "+s"(src));
@@ -815,12 +973,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) 
         multiply(1);
     };
     // prologue in steady-state order: W(0) | H(0) W(1) | H(1) W(2)
-    if (0 < n_super) issue_w(0);
-    if (0 < n_super) issue_h(0);
-    if (1 < n_super) issue_w(1);
-    if (1 < n_super) issue_h(1);
-    if (2 < n_super) issue_w(2);
-    int S = 0;
+    int S = s_begin;
+    if (S < n_super) issue_w(S);
+    if (S < n_super) issue_h(S);
+    if (S + 1 < n_super) issue_w(S + 1);
+    if (S + 1 < n_super) issue_h(S + 1);
+    if (S + 2 < n_super) issue_w(S + 2);
     for (; S + 3 < n_super; ++S) {          // steady state: W(S+1), H(S+1), W(S+2) stay in flight across the barrier
         wait_and_meet<2 * WPASSES + 1>();
         issue_h(S + 2);
@@ -833,6 +991,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_lm_head_skinny(LmHeadParams p) 
         compute(S);
     }
 
+    if constexpr (STORE) {
+        if (wave_works) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                store_tile16<F16>(acc[mt], 32 * mt + r, n0 + 32 * wv + 4 * h, slice, p);
+        }
+        return;
+    }
     // ---- epilogue: per wave 64 rows x 32 columns -> (m2, s, g, arg-max); waves 1..7 hand theirs to wave 0 through LDS
     float* const meet = reinterpret_cast<float*>(lds);   // [7 waves][64 rows][kMsg]
     __syncthreads();
@@ -1180,4 +1346,136 @@ ASD_EXPORT int asd_lm_head_pack_weights(const void* weight, int64_t ld_w, int dt
     hipLaunchKernelGGL(k_pack_lm_head, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const char*>(weight), ld_w, V, D, static_cast<char*>(packed), n_seg);
     return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// asd_linear: y[M][N] = x[M][D] . w[N][D]^T (+ bias) -- the projections of the decoder layers around the path (the callers'
+// side), on the SAME three kernels with the STORE epilogue:
+//   M <= 64    k_lm_head_skinny (stream-shaped: the call is HBM-bound)     column blocks x reduction slices
+//   M <= 256   k_lm_head_tile<4> (8 waves, 256 x 256)                       column blocks x reduction slices
+//   M  > 256   k_lm_head_quad (4 waves x 128 x 128, row blocks share a weight tile through the XCD's L2)
+// A layer's matrices are narrow (N = 3584 .. 57344: 14 .. 224 column blocks of 256) next to the lm_head's 594, so the
+// reduction is cut into slices until the grid fills the CUs; the slices write f32 partials ([slice][M][N], L2 / MALL
+// resident) and k_linear_reduce adds them in slice order (bit-reproducible), adds the bias and rounds once.
+namespace {
+struct LinearPlan {
+    int kind;        // 0 skinny, 1 tile, 2 quad
+    int k_slices;
+    int64_t units;   // workgroups before slicing
+};
+
+LinearPlan linear_plan(int M, int N, int D) {
+    LinearPlan pl{};
+    const int64_t blocks = (static_cast<int64_t>(N) + 255) / 256;
+    const int64_t m_blocks = (static_cast<int64_t>(M) + kBM - 1) / kBM;
+    const int64_t cus = current_device_cus() > 0 ? current_device_cus() : 256;
+    // M > 64: the 8-wave kernel with reduction slices (a short last row block runs the 2 x 4 / 1 x 8 wave forms); the 4-wave
+    // kernel only where its unsliced grid fills the CUs twice over (it is the MFMA-bound form: 0.95-1.0 PF on the lm_head)
+    pl.kind = M <= kSkRows ? 0 : ((m_blocks >= 2 && blocks * m_blocks >= 2 * cus) ? 2 : 1);
+    pl.units = blocks * m_blocks;
+    pl.k_slices = 1;
+    // cost of a plan in superstages per CU: rounds x (superstages of a slice + pipeline fill) (+ the slab round trip)
+    const int total = D / kSuper;
+    // Cost of a plan in superstage-times of one CU.  A workgroup of a sliced launch pays its share of the reduction, the
+    // pipeline fill, and the slab round trip: rows x 256 columns x 4 B written and read again = rows / 16 superstages' worth
+    // of bytes (2 at M = 32, 16 for a full 256-row block -- slicing a wide, tall product costs more than it balances).
+    // Makespan: whole rounds of the FULL workgroups (a CU holds one), or the total work spread over the CUs if that is
+    // more; a last row block of <= 64 / <= 128 rows counts as a quarter / half of a workgroup.
+    const int fill = 3;
+    const int rows_eff = M < kBM ? M : kBM;
+    const int slab = (rows_eff + 15) / 16;
+    int64_t full_units = pl.units, rem_units = 0, rem_quarters = 0;
+    if (pl.kind != 0) {
+        const int rem = M - static_cast<int>(m_blocks - 1) * kBM;
+        if (rem <= 128) {
+            full_units = blocks * (m_blocks - 1);
+            rem_units = blocks;
+            rem_quarters = rem <= 64 ? 1 : 2;
+        }
+    }
+    double best = -1.0;
+    for (int sl = 1; sl <= 32 && sl <= total; ++sl) {
+        const double t_unit = static_cast<double>((total + sl - 1) / sl + fill + (sl > 1 ? slab : 0));
+        const double by_rounds = static_cast<double>((full_units * sl + cus - 1) / cus) * t_unit;
+        const double by_work = (static_cast<double>(full_units) + 0.25 * rem_quarters * static_cast<double>(rem_units)) * sl * t_unit / cus;
+        double cost = by_rounds > by_work ? by_rounds : by_work;
+        if (full_units == 0) cost = static_cast<double>((rem_units * sl + cus - 1) / cus) * t_unit;   // one short row block only
+        if (best < 0.0 || cost < best) { best = cost; pl.k_slices = sl; }
+    }
+    return pl;
+}
+}  // namespace
+
+ASD_EXPORT size_t asd_linear_workspace_bytes(int M, int N, int D) {
+    if (M <= 0 || N <= 0 || D <= 0 || D % kSuper != 0) return 0;
+    const LinearPlan pl = linear_plan(M, N, D);
+    const size_t slabs = pl.k_slices > 1 ? static_cast<size_t>(pl.k_slices) * M * static_cast<size_t>(N) * sizeof(float) : 0;
+    return round_up(slabs, 256) + 256;
+}
+
+ASD_EXPORT int asd_debug_linear_slices(int M, int N, int D) {      // the plan's slice count (tests, tools)
+    if (M <= 0 || N <= 0 || D <= 0 || D % kSuper != 0) return 0;
+    return linear_plan(M, N, D).k_slices;
+}
+
+namespace {
+int g_force_linear_slices = 0;
+}
+ASD_EXPORT int asd_debug_force_linear_slices(int k) {      // 0: the plan's own choice; returns the previous value
+    const int old = g_force_linear_slices;
+    g_force_linear_slices = k < 0 ? 0 : k;
+    return old;
+}
+
+ASD_EXPORT int asd_linear_ex(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, const void* residual,
+                             int64_t ld_res, int dtype, int M, int N, int D, void* y, int64_t ld_y, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (M < 0 || N < 1 || D < 1) return ASD_ERR_INVALID_ARG;
+    if (residual && (ld_res < N || ld_res % 4 != 0 || !aligned_to(residual, 8))) return ld_res < N ? ASD_ERR_INVALID_ARG : ASD_ERR_ALIGNMENT;
+    if (M == 0) return ASD_OK;
+    if ((dtype != ASD_DTYPE_BF16 && dtype != ASD_DTYPE_F16) || D % kSuper != 0 || N % 4 != 0) return ASD_ERR_UNSUPPORTED;
+    if (!x || !w || !y || ld_x < D || ld_w < D || ld_y < N) return ASD_ERR_INVALID_ARG;
+    if (!aligned_to(x, 16) || !aligned_to(w, 16) || !aligned_to(y, 8) || (bias && !aligned_to(bias, 8)) || ld_x % 8 != 0 ||
+        ld_w % 8 != 0 || ld_y % 4 != 0)
+        return ASD_ERR_ALIGNMENT;
+    const bool f16 = dtype == ASD_DTYPE_F16;
+    LinearPlan pl = linear_plan(M, N, D);
+    if (g_force_linear_slices > 0) pl.k_slices = g_force_linear_slices <= D / kSuper ? g_force_linear_slices : D / kSuper;
+    const size_t slab_bytes = pl.k_slices > 1 ? static_cast<size_t>(pl.k_slices) * M * static_cast<size_t>(N) * sizeof(float) : 0;
+    if (slab_bytes > 0 && (!workspace || workspace_bytes < slab_bytes)) return ASD_ERR_WORKSPACE;
+    if (slab_bytes > 0 && !aligned_to(workspace, 16)) return ASD_ERR_ALIGNMENT;
+    if (pl.units * pl.k_slices >= (1ll << 31) || static_cast<int64_t>(M) * N / 4 / 256 >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
+
+    LmHeadParams p{};
+    p.hidden = x; p.ld_h = ld_x; p.weight = w; p.ld_w = ld_w;
+    p.D = D; p.M = M; p.V = N;
+    p.m_blocks = (M + kBM - 1) / kBM;
+    p.n_blocks = (N + 255) / 256;
+    p.k_slices = pl.k_slices;
+    p.slabs = static_cast<float*>(workspace);
+    p.out = y; p.ld_out = ld_y; p.bias = bias; p.residual = residual; p.ld_res = ld_res;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(static_cast<unsigned>(pl.units * pl.k_slices));
+    if (pl.kind == 0) {
+        if (f16) hipLaunchKernelGGL((k_lm_head_skinny<true, true>), grid, dim3(kThreads), 0, st, p);
+        else hipLaunchKernelGGL((k_lm_head_skinny<false, true>), grid, dim3(kThreads), 0, st, p);
+    } else if (pl.kind == 1) {
+        if (f16) hipLaunchKernelGGL(k_linear_tile<true>, grid, dim3(kThreads), 0, st, p);
+        else hipLaunchKernelGGL(k_linear_tile<false>, grid, dim3(kThreads), 0, st, p);
+    } else {
+        if (f16) hipLaunchKernelGGL((k_lm_head_quad<true, true>), grid, dim3(kQThreads), 0, st, p);
+        else hipLaunchKernelGGL((k_lm_head_quad<false, true>), grid, dim3(kQThreads), 0, st, p);
+    }
+    if (pl.k_slices > 1) {
+        const int64_t n_threads = static_cast<int64_t>(M) * (N / 4);
+        const dim3 rgrid(static_cast<unsigned>((n_threads + 255) / 256));
+        if (f16) hipLaunchKernelGGL(k_linear_reduce<true>, rgrid, dim3(256), 0, st, p.slabs, pl.k_slices, M, N, bias, residual, ld_res, y, ld_y);
+        else hipLaunchKernelGGL(k_linear_reduce<false>, rgrid, dim3(256), 0, st, p.slabs, pl.k_slices, M, N, bias, residual, ld_res, y, ld_y);
+    }
+    return launch_status();
+}
+
+ASD_EXPORT int asd_linear(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, int dtype, int M, int N,
+                          int D, void* y, int64_t ld_y, void* workspace, size_t workspace_bytes, void* stream) {
+    return asd_linear_ex(x, ld_x, w, ld_w, bias, nullptr, 0, dtype, M, N, D, y, ld_y, workspace, workspace_bytes, stream);
 }

@@ -266,6 +266,51 @@ class LmHeadVerifier:
         return msg
 
 
+class LinearWorkspace:
+    """Slab buffer of asd_linear's reduction slices; grows to the largest (M, N, D) it has served.  One per stream:
+    consecutive calls on a stream may share it."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.buf: Optional[torch.Tensor] = None
+
+    def ensure(self, M: int, N: int, D: int) -> Tuple[int, int]:
+        need = int(_lib().asd_linear_workspace_bytes(M, N, D))
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self.buf.data_ptr(), self.buf.numel()
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, workspace: LinearWorkspace,
+           out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """X2: y = x @ weight.T (+ bias) (+ residual) through asd_linear_ex.  x [..., D], weight [N, D] (nn.Linear layout), all bf16
+    or all f16 CUDA tensors; returns [..., N] of the same type.  residual [M, N] may be `out` itself (in-place accumulate)."""
+    if weight.dim() != 2 or weight.dtype not in (torch.bfloat16, torch.float16) or not weight.is_cuda or weight.stride(1) != 1:
+        raise ValueError("weight must be a [N, D] bf16 or f16 CUDA tensor with contiguous rows")
+    if x.dtype != weight.dtype or not x.is_cuda or x.shape[-1] != weight.shape[1]:
+        raise ValueError("x must be a CUDA tensor of the weight's element type with D trailing elements")
+    N, D = weight.shape
+    x2 = x.reshape(-1, D)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    elif out.shape != (M, N) or out.dtype != x.dtype or out.stride(1) != 1:
+        raise ValueError("out must be a [M, N] tensor of the operands' type with contiguous rows")
+    if bias is not None and (bias.dtype != x.dtype or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("bias must be a contiguous [N] tensor of the operands' type")
+    if residual is not None and (residual.shape != (M, N) or residual.dtype != x.dtype or residual.stride(1) != 1):
+        raise ValueError("residual must be a [M, N] tensor of the operands' type with contiguous rows")
+    ws_ptr, ws_bytes = workspace.ensure(M, N, D)
+    rc = _lib().asd_linear_ex(x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0),
+                              None if bias is None else bias.data_ptr(), None if residual is None else residual.data_ptr(),
+                              0 if residual is None else residual.stride(0), _DTYPE_CODE[x.dtype], M, N, D, out.data_ptr(),
+                              out.stride(0), ws_ptr, ws_bytes, _stream())
+    B.check("asd_linear_ex", rc)
+    return out.view(*x.shape[:-1], N)
+
+
 def commit_step(tok: torch.Tensor, n_acc: torch.Tensor, drawn: torch.Tensor, seq_len: torch.Tensor,
                 out_tokens: torch.Tensor, n_commit: Optional[torch.Tensor] = None, max_len: Optional[int] = None) -> None:
     """N3: append every sequence's accepted prefix + drawn token to its row of `out_tokens` and advance

@@ -815,14 +815,17 @@ def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[Draft
 def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: HierarchyConfig, prompt_ids: torch.Tensor,
                      max_new_tokens: int, predictor, ops=None, dtype: torch.dtype = torch.bfloat16,
                      heads: Sequence[str] = ("logits", "fused"), logit_scale: float = 1.0, seeds: Sequence[int] = (1, 2, 3),
-                     keep_inputs: bool = False, weight_noise: Sequence[float] = (0.0, 0.0, 0.0), share_seed: Optional[int] = None
-                     ) -> Tuple[Optional[DraftRole], Dict[int, VerifyRole]]:
+                     keep_inputs: bool = False, weight_noise: Sequence[float] = (0.0, 0.0, 0.0), share_seed: Optional[int] = None,
+                     hip_layers: Optional[bool] = None) -> Tuple[Optional[DraftRole], Dict[int, VerifyRole]]:
     """The roles `rank` hosts under `placement`: tier 0 + verify tiers, models built on prompt_ids.device.
     shapes: one synthetic_lm.LMShape per tier.  heads[s-1]: "logits" (lm_head GEMM + asd_verify_accept), "fused"
     (asd_lm_head_verify from hidden states); a tier placed on several ranks gets a ShardedHead over those ranks
     (every rank of the tier must call this function: it creates the tier's process group).
     share_seed: all tiers start from the same seed (+ per-tier lm_head noise `weight_noise`) -- small test models
-    that agree often enough to accept tokens."""
+    that agree often enough to accept tokens.
+    hip_layers: run the models' passes through asd_decoder_forward (serving/hip_decoder.py) instead of torch modules.  None:
+    wherever the stack supports the model (CUDA, bf16, head_dim 128 -- every Qwen2.5 shape); True: required (raises
+    otherwise); False: torch modules.  `model.execution` on every role's model says which one it got."""
     from .synthetic_lm import SyntheticLM
     ops = ops if ops is not None else HipOps()
     dev = prompt_ids.device
@@ -832,6 +835,9 @@ def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: Hie
     def make(i):
         m = SyntheticLM(shapes[i], dtype=dtype, device=dev, seed=share_seed if share_seed is not None else seeds[i],
                         logit_scale=logit_scale)
+        can = dev.type == "cuda" and dtype == torch.bfloat16 and shapes[i].head_dim == 128
+        if hip_layers or (hip_layers is None and can):
+            m.enable_hip_layers()
         if weight_noise[i]:
             g = torch.Generator(device=dev).manual_seed(1000 + i)
             with torch.no_grad():

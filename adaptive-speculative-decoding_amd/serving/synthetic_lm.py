@@ -177,6 +177,12 @@ class SyntheticLM(nn.Module):
         self._len = 0
         self._ragged = None
         self._graphs = None                    # enable_graphs(): {(B, T, return_hidden): (hipGraph, ids, pos0, out)}
+        self._hip = None                       # enable_hip_layers(): serving.hip_decoder.HipDecoder
+
+    @property
+    def execution(self) -> str:
+        """Which code runs forward_ragged: "hip_decoder" (asd_decoder_forward) or "torch_modules"."""
+        return "hip_decoder" if self._hip is not None else "torch_modules"
 
     # -- cache management
     def reset(self):
@@ -195,8 +201,23 @@ class SyntheticLM(nn.Module):
         self._graphs = {} if on else None
         self._max_graphs = int(max_graphs)
 
+    def enable_hip_layers(self, on: bool = True) -> None:
+        """Run forward_ragged through asd_decoder_forward (X2: csrc/decoder.hip + asd_linear; nine launches per layer, one host
+        call per pass) instead of the torch modules.  CUDA + bf16 + head_dim 128 only; raises otherwise -- no fallback.  Call
+        before alloc_ragged.  The lock-step `forward` / `truncate` cache keeps the torch modules."""
+        if on:
+            from .hip_decoder import HipDecoder
+            self._hip = HipDecoder(self)
+        else:
+            self._hip = None
+        self._ragged = None
+
     def alloc_ragged(self, batch: int, max_len: int):
         """Per-sequence KV cache (N3): one [B, Hkv, max_len, hd] K and V buffer per layer, zero-filled."""
+        if self._hip is not None:
+            self._hip.alloc(batch, max_len)
+            self._ragged = "hip"
+            return
         p = next(self.parameters())
         shape = (batch, self.shape.kv_heads, max_len, self.shape.head_dim)
         self._ragged = [(torch.zeros(shape, dtype=p.dtype, device=p.device), torch.zeros(shape, dtype=p.dtype, device=p.device))
@@ -217,10 +238,13 @@ class SyntheticLM(nn.Module):
                 return self._forward_ragged_graphed(key, ids, pos0, return_hidden)
         return self._forward_ragged_eager(ids, pos0, window, return_hidden, rows)
 
+    def _cap(self) -> int:
+        return self._hip.t_max if self._hip is not None else self._ragged[0][0].shape[2]
+
     def _forward_ragged_graphed(self, key, ids, pos0, return_hidden):
         g = self._graphs.get(key)
         if g is None:
-            cap = self._ragged[0][0].shape[2]
+            cap = self._cap()
             sid, spos = ids.clone(), pos0.to(torch.int64).clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -239,6 +263,8 @@ class SyntheticLM(nn.Module):
         return out
 
     def _forward_ragged_eager(self, ids, pos0, window, return_hidden, rows):
+        if self._hip is not None:
+            return self._hip.forward(ids, pos0, return_hidden, rows)
         B, T = ids.shape
         cap = self._ragged[0][0].shape[2]
         window = min(window, cap)

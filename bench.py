@@ -236,8 +236,11 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
     cfg = H.HierarchyConfig(draft_len=K, temperature=0.7, top_p=0.9, lambda_value=lam if lam else 1.0e6, seed=seed)
     ops = _timed_ops(torch)
     t0 = time.perf_counter()
+    # model execution: the HIP decoder stack (asd_decoder_forward: 9 launches per layer) unless ASD_LOOP_TORCH_MODULES=1 asks
+    # for the torch modules of rounds 1-3 (~50 launches per layer) as the comparison
+    hip_layers = False if os.environ.get("ASD_LOOP_TORCH_MODULES", "0") == "1" else None
     draft, tiers = H.build_rank_roles(rank, pl, shp, cfg, prompt, new_tokens, pred, ops=ops, heads=heads,
-                                      logit_scale=logit_scale, seeds=(1, 2, 3))
+                                      logit_scale=logit_scale, seeds=(1, 2, 3), hip_layers=hip_layers)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     L = len(shp)
@@ -367,7 +370,9 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
         "hot_path_share": hot_ms / (1e3 * elapsed), "build_s": build_s,
         "roofline": loop_roof, "model_ms": model_ms, "model_passes_from_hipgraphs": graphs_on,
         "lambda_history": tr.lambda_history, "tier_forwards": tr.tier_forwards,
-        "models": "synthetic random-weight Qwen2.5 shapes (torch / hipBLASLt; third-party in the reference), logit_scale "
+        "model_execution": {("tier0_draft" if r_ is draft else f"tier{r_.s}"): r_.m.execution
+                            for r_ in ([draft] if draft is not None else []) + [tiers[k_] for k_ in sorted(tiers)]},
+        "models": "synthetic random-weight Qwen2.5 shapes (third-party in the reference), logit_scale "
                   f"{logit_scale} so that unrelated random models still accept tokens; KV per sequence (ragged)",
     }
     return rec
@@ -395,8 +400,12 @@ def sharded_target_loop(torch, dist, device, rank, world, shapes, B_local, K, pr
     ops = _timed_ops(torch)
     t0 = time.perf_counter()
     dm = SyntheticLM(d_shape, dtype=torch.bfloat16, device=device, seed=1, logit_scale=logit_scale)
+    if os.environ.get("ASD_LOOP_TORCH_MODULES", "0") != "1" and d_shape.head_dim == 128:
+        dm.enable_hip_layers()
     draft = H.DraftRole(dm, cfg, ops, prompt[b0:b1].contiguous(), new_tokens, pred, batch_total=Bt, batch_offset=b0)
     tm = SyntheticLM(t_shape, dtype=torch.bfloat16, device=device, seed=3, logit_scale=logit_scale)
+    if os.environ.get("ASD_LOOP_TORCH_MODULES", "0") != "1" and t_shape.head_dim == 128:
+        tm.enable_hip_layers()
     head = H.ShardedHead(tm, ops, V, group=None)
     tm.lm_head.weight = torch.nn.Parameter(tm.lm_head.weight[head.v0:head.v1].clone(), requires_grad=False)
     torch.cuda.empty_cache()

@@ -189,6 +189,74 @@ int asd_lm_head_partial(const void* hidden, int64_t ld_h, const void* weight_sha
                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * X2 (callers' side of the path)  y[M][N] = x[M][D] . w[N][D]^T (+ bias[N]): the nn.Linear projections of the
+ * decoder layers the reference runs through transformers / vLLM (third party there: src/serving/real_model_pipeline.py:135,
+ * src/models/stage.py) -- the step that produces the hidden states asd_lm_head_verify consumes and, for the draft tier, the
+ * logits asd_draft_sample consumes.  The lm_head kernels' main loops with a STORE epilogue; narrow matrices are cut into
+ * reduction slices whose f32 partials meet in `workspace` and are added in slice order (bit-reproducible).
+ * x, w, bias (may be NULL), y: all bf16 or all f16 (dtype); f32 accumulation, ONE rounding at the store.
+ * D % 64 == 0, N % 4 == 0, x / w 16-byte aligned with ld % 8 == 0, y 8-byte aligned with ld_y % 4 == 0.
+ * workspace: asd_linear_workspace_bytes(M, N, D) bytes (no initialisation needed; may be shared by calls on one stream). */
+size_t asd_linear_workspace_bytes(int M, int N, int D);
+int asd_linear(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, int dtype, int M, int N, int D,
+               void* y /*[M][ld_y] out*/, int64_t ld_y, void* workspace, size_t workspace_bytes, void* stream);
+/* ... + residual[M][ld_res] (may be NULL; may alias y: y = y + x . w^T, the decoder layer's residual connection) */
+int asd_linear_ex(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, const void* residual,
+                  int64_t ld_res, int dtype, int M, int N, int D, void* y /*[M][ld_y] out*/, int64_t ld_y, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* test hooks: the reduction slices the launcher would use; force a count (0 = the launcher's own choice; process-wide) */
+int asd_debug_linear_slices(int M, int N, int D);
+int asd_debug_force_linear_slices(int k_slices);   /* returns the previous value */
+
+/* ------------------------------------------------------------------------------------------
+ * X2, continued: the rest of a decoder layer around the projections, for the M = B * T positions a tier is fed in one pass
+ * (row m = b * T + t), over a per-sequence KV cache.  bf16 only; head_dim 128 (every Qwen2.5 shape).
+ *   asd_rmsnorm        out = x * rsqrt(mean(x^2) + eps) * weight, f32 arithmetic, one rounding; D % 8 == 0, D <= 8192
+ *   asd_rope_kv_store  qkv [M][ld] = q heads | k heads | v heads: rotary embedding (half-split pairs (i, i + 64), angle
+ *                      pos[m] * inv_freq[i]) of q IN PLACE and of k INTO the cache; v into the TRANSPOSED cache
+ *                        k_cache  [cache rows][KVH][t_max][128]      vt_cache [cache rows][KVH][128][t_max]
+ *                      cache row of sequence b: rows[b] (rows == NULL: b); pos is clamped to [0, t_max - 1]; t_max % 32 == 0
+ *   asd_attn_ragged    out[m][head] = softmax_j<=pos[m] (q . k_j / sqrt(128)) v_j over the cache of sequence m / T (grouped
+ *                      queries: head / (H / KVH) picks the kv head); MFMA flash-decode, both cache operands read in operand
+ *                      layout straight from global memory (that is what the transposed V cache is for)
+ *   asd_silu_mul       act[m][i] = silu(gate_up[m][i]) * gate_up[m][I + i]
+ *   asd_decoder_forward  n_layers x (rmsnorm, qkv, rope + cache write, attention, o + residual, rmsnorm, gate | up, silu * up,
+ *                      down + residual) on x [M][ld_x] in place -- nine launches per layer, all issued by this one call.
+ * Entries of the caches past a sequence's committed length are rewritten before they are read (KV rollback = a length
+ * update, asd_commit_step); the caches must hold finite values from the start (zero-fill them once). */
+typedef struct asd_layer {
+    const void* ln1_w;      /* [hidden] */
+    const void* qkv_w;      /* [hidden + 2 * KVH * 128][hidden]: q | k | v projection rows */
+    const void* qkv_b;      /* [hidden + 2 * KVH * 128] or NULL */
+    const void* o_w;        /* [hidden][hidden] */
+    const void* ln2_w;      /* [hidden] */
+    const void* gate_up_w;  /* [2 * intermediate][hidden]: gate rows, then up rows */
+    const void* down_w;     /* [hidden][intermediate] */
+    void* k_cache;
+    void* vt_cache;
+} asd_layer_t;
+typedef struct asd_decoder_shape {
+    int hidden, heads, kv_heads, head_dim, intermediate;
+    float rms_eps;
+    const float* inv_freq;  /* [64] f32, device: theta^(-2 i / 128) */
+    int t_max;              /* positions per cache row */
+} asd_decoder_shape_t;
+int asd_rmsnorm(const void* x, int64_t ld_x, const void* weight, float eps, int dtype, int M, int D, void* out /*[M][ld_out]*/,
+                int64_t ld_out, void* stream);
+int asd_rope_kv_store(void* qkv /*[B*T][ld_qkv] in/out*/, int64_t ld_qkv, const int32_t* pos /*[B*T]*/,
+                      const int32_t* rows /*[B] or NULL*/, const float* inv_freq /*[64]*/, int dtype, int B, int T, int H, int KVH,
+                      int head_dim, void* k_cache, void* vt_cache, int t_max, void* stream);
+int asd_attn_ragged(const void* qkv, int64_t ld_qkv, const void* k_cache, const void* vt_cache, const int32_t* pos,
+                    const int32_t* rows, int dtype, int B, int T, int H, int KVH, int head_dim, int t_max,
+                    void* out /*[B*T][ld_out], H * 128 wide*/, int64_t ld_out, void* stream);
+int asd_silu_mul(const void* gate_up /*[M][ld_gu], 2 I wide*/, int64_t ld_gu, int dtype, int M, int I, void* act /*[M][ld_act]*/,
+                 int64_t ld_act, void* stream);
+size_t asd_decoder_scratch_bytes(const asd_decoder_shape_t* shape, int M);
+int asd_decoder_forward(const asd_layer_t* layers, int n_layers, const asd_decoder_shape_t* shape, void* x /*[B*T][ld_x] in/out*/,
+                        int64_t ld_x, const int32_t* pos, const int32_t* rows, int B, int T, void* scratch /*256-byte aligned*/,
+                        size_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * N3  commit / KV rollback bookkeeping of one token-level step, on the device.
  * The reference's src/serving/cache_manager.py:149-190 `truncate_at_stage` trims a dict of strings;
  * with a per-sequence KV cache the rollback after a rejection is a length update.  Row b of the token

@@ -1,0 +1,113 @@
+"""X2: asd_linear (y = x . w^T + bias through the lm_head kernels' main loops with a STORE epilogue) against an f64 product of
+the same bf16 / f16 operands.  Floating point: the kernel accumulates in f32 (MFMA order) and rounds ONCE to the operand
+type, so the bound is half an output ulp (2^-9 relative for bf16, 2^-12 for f16) plus the f32 accumulation error -- written
+below as  |y - ref| <= 2^-8 |ref| + 2e-4  (bf16)  /  2^-11 |ref| + 2e-4  (f16)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(M, N, D, dtype, bias, seed, ld_pad=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(M, D + ld_pad, generator=g, device="cuda", dtype=torch.float32).to(dtype)[:, :D]
+    w = (torch.randn(N, D + ld_pad, generator=g, device="cuda", dtype=torch.float32) / D ** 0.5).to(dtype)[:, :D]
+    b = torch.randn(N, generator=g, device="cuda", dtype=torch.float32).to(dtype) if bias else None
+    return x, w, b
+
+
+def _ref(x, w, b):
+    r = x.double() @ w.double().T
+    return r if b is None else r + b.double()
+
+
+def _check(y, ref, dtype):
+    rel = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (y.double() - ref).abs()
+    bound = rel * ref.abs() + 2e-4
+    assert bool((err <= bound).all()), f"max excess {(err - bound).max().item():.3e}"
+
+
+SHAPES = [
+    # M, N, D, bias
+    (1, 3584, 3584, False), (8, 4608, 3584, True), (32, 3584, 3584, False), (32, 512, 3584, True),
+    (33, 1004, 128, True), (64, 3584, 18944, False), (65, 3584, 3584, True), (128, 7168, 5120, True),
+    (200, 5120, 5120, False), (256, 1004, 192, True), (288, 5120, 5120, False), (288, 7168, 5120, True), (520, 2052, 1024, True),
+]
+
+
+@pytest.mark.parametrize("M,N,D,bias", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear_matches_f64_product(M, N, D, bias, dtype):
+    from importlib import import_module
+    K_ = import_module("adaptive-speculative-decoding_amd.kernels")
+    x, w, b = _mk(M, N, D, dtype, bias, seed=M * 7 + N)
+    ws = K_.LinearWorkspace("cuda")
+    y = K_.linear(x, w, b, workspace=ws)
+    assert y.shape == (M, N) and y.dtype == dtype
+    _check(y, _ref(x, w, b), dtype)
+    y2 = K_.linear(x, w, b, workspace=ws)
+    assert torch.equal(y, y2)                     # slices are added in slice order: the same bits on every call
+
+
+def test_linear_strided_operands_and_out():
+    from importlib import import_module
+    K_ = import_module("adaptive-speculative-decoding_amd.kernels")
+    x, w, b = _mk(32, 3584, 3584, torch.bfloat16, True, seed=5, ld_pad=64)     # rows 64 elements apart from contiguous
+    assert x.stride(0) == 3584 + 64 and w.stride(0) == 3584 + 64
+    ws = K_.LinearWorkspace("cuda")
+    big = torch.full((32, 4000), 7.0, device="cuda", dtype=torch.bfloat16)
+    out = big[:, :3584]
+    K_.linear(x, w, b, workspace=ws, out=out)
+    _check(out, _ref(x, w, b), torch.bfloat16)
+    assert bool((big[:, 3584:] == 7.0).all())                                    # nothing written past N
+
+
+@pytest.mark.parametrize("M,N,D", [(32, 3584, 3584), (32, 37888, 3584), (288, 5120, 5120), (288, 55296, 5120)])
+def test_linear_residual_in_place(M, N, D):
+    from importlib import import_module
+    K_ = import_module("adaptive-speculative-decoding_amd.kernels")
+    x, w, b = _mk(M, N, D, torch.bfloat16, True, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    res = torch.randn(M, N, generator=g, device="cuda").to(torch.bfloat16)
+    ref = _ref(x, w, b) + res.double()
+    ws = K_.LinearWorkspace("cuda")
+    y = K_.linear(x, w, b, workspace=ws, residual=res)
+    _check(y, ref, torch.bfloat16)
+    acc = res.clone()
+    K_.linear(x, w, b, workspace=ws, out=acc, residual=acc)        # y aliases the residual
+    assert torch.equal(acc, y)
+
+
+@pytest.mark.parametrize("M", [32, 200, 288])
+def test_linear_slice_counts_agree(M):
+    """Forced reduction-slice counts (1 = no slabs, direct store) differ only in the f32 summation order."""
+    from importlib import import_module
+    K_ = import_module("adaptive-speculative-decoding_amd.kernels")
+    lib = K_._lib()
+    x, w, b = _mk(M, 3584, 3584, torch.bfloat16, True, seed=11)
+    ref = _ref(x, w, b)
+    ws = K_.LinearWorkspace("cuda")
+    assert lib.asd_debug_linear_slices(M, 3584, 3584) > 1       # a 14-block matrix cannot fill the CUs unsliced
+    try:
+        for k in (1, 2, 7, 56):
+            lib.asd_debug_force_linear_slices(k)
+            ws.buf = torch.empty(56 * M * 3584 * 4 + 512, dtype=torch.uint8, device="cuda")
+            y = K_.linear(x, w, b, workspace=ws)
+            _check(y, ref, torch.bfloat16)
+    finally:
+        lib.asd_debug_force_linear_slices(0)
+
+
+def test_linear_argument_checks():
+    from importlib import import_module
+    K_ = import_module("adaptive-speculative-decoding_amd.kernels")
+    B_ = import_module("adaptive-speculative-decoding_amd._binding")
+    ws = K_.LinearWorkspace("cuda")
+    x, w, _ = _mk(4, 1004, 128, torch.bfloat16, False, seed=1)
+    with pytest.raises(B_.AsdError):                       # D % 64 != 0
+        K_.linear(x[:, :100].contiguous(), w[:, :100].contiguous(), workspace=ws)
+    with pytest.raises(B_.AsdError):                       # N % 4 != 0
+        K_.linear(x, w[:1001], workspace=ws)
+    with pytest.raises(ValueError):
+        K_.linear(x.float(), w, workspace=ws)
