@@ -61,13 +61,14 @@ SIGNATURES = {
     "asd_linear_workspace_bytes": (_sz, [_i, _i, _i]),
     "asd_linear": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
     "asd_linear_ex": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
+    "asd_linear_partial": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp, _vp]),
     "asd_debug_linear_slices": (_i, [_i, _i, _i]),
     "asd_rmsnorm": (_i, [_vp, _i64, _vp, _f, _i, _i, _i, _vp, _i64, _vp]),
     "asd_rope_kv_store": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "asd_attn_ragged": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
     "asd_silu_mul": (_i, [_vp, _i64, _i, _i, _i, _vp, _i64, _vp]),
     "asd_decoder_scratch_bytes": (_sz, [_vp, _i]),
-    "asd_decoder_forward": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "asd_decoder_forward": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "asd_debug_force_linear_slices": (_i, [_i]),
     "asd_lm_head_partial": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
     "asd_commit_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),

@@ -6,7 +6,9 @@
 //   k_rmsnorm -> asd_linear (qkv, bias) -> k_rope_kv_store -> k_attn_ragged -> asd_linear (o, + residual, in place)
 //   k_rmsnorm -> asd_linear (gate | up)  -> k_silu_mul     -> asd_linear (down, + residual, in place)
 //
-// and asd_decoder_forward issues all layers from ONE host call.
+// and asd_decoder_forward issues all layers from ONE host call.  Where a projection's plan cuts the reduction into slices
+// (narrow matrices: 14 column blocks cannot feed 256 CUs) the kernel that FOLLOWS it adds the f32 partials itself -- rope after
+// q|k|v, the next norm (with the residual connection) after o and down, silu * up after gate|up -- so no reduce kernel runs.
 //
 // KV cache per layer: K as [rows][KVH][Tmax][128] and V TRANSPOSED, [rows][KVH][128][Tmax]: with the keys of a 32-key tile
 // permuted (kappa below) both products of the attention take their cache operand straight from global memory in the MFMA
@@ -30,54 +32,107 @@ __device__ __forceinline__ uint32_t pack_bf(float a, float b) {
     return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, x)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, y)) << 16);
 }
 
-// ---- RMSNorm: out = (x * rsqrt(mean(x^2) + eps) * w) in f32, one rounding.  One workgroup per row, D <= 8192, D % 8 == 0.
-__global__ __launch_bounds__(256) void k_rmsnorm(const char* __restrict__ x, int64_t ld_x, const char* __restrict__ w, float eps,
-                                                 char* __restrict__ out, int64_t ld_out, int D) {
-    __shared__ float part[4];
+// A sliced asd_linear_partial leaves f32 partials [k_slices][M][N]; the kernels below can take their input from there instead
+// of from the rounded [M][N] matrix: slices added in slice order, then the bias, then (where the layer has one) the residual,
+// ONE rounding to bf16 -- the order and the rounding of asd_linear_ex's own reduce kernel, so either way gives the same bits.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct Slabs {
+    const float* base;     // NULL: no slabs, read the matrix
+    int k_slices;
+    int64_t stride;        // M * N
+    int N;
+};
+__device__ __forceinline__ float slab_sum1(const Slabs& z, int m, int n) {
+    const float* p = z.base + static_cast<int64_t>(m) * z.N + n;
+    float acc = p[0];
+#pragma unroll 4
+    for (int sl = 1; sl < z.k_slices; ++sl) acc += p[sl * z.stride];     // (unrolled: the loads go out together, the adds keep slice order)
+    return acc;
+}
+__device__ __forceinline__ void slab_sum8(const Slabs& z, int m, int n, float (&v)[8]) {
+    const float* p = z.base + static_cast<int64_t>(m) * z.N + n;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll 4
+    for (int sl = 1; sl < z.k_slices; ++sl) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p + sl * z.stride), d = *reinterpret_cast<const f32x4*>(p + sl * z.stride + 4);
+        a[0] += c[0]; a[1] += c[1]; a[2] += c[2]; a[3] += c[3];
+        b[0] += d[0]; b[1] += d[1]; b[2] += d[2]; b[3] += d[3];
+    }
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+// ---- RMSNorm: out = (x * rsqrt(mean(x^2) + eps) * w) in f32, one rounding.  One workgroup of 1024 threads per row, 4-element
+// pieces (a row of 3584 is 896 pieces: one per thread), D <= 8192, D % 4 == 0.
+// SLABS: first x[m] = round(sum of the slabs + x[m]) is formed and written back -- the o / down projection's residual connection,
+// fused with the norm that follows it (each thread adds the k_slices partials of its piece).
+__device__ __forceinline__ void slab_sum4(const Slabs& z, int m, int n, float (&v)[4]) {
+    const float* p = z.base + static_cast<int64_t>(m) * z.N + n;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll 4
+    for (int sl = 1; sl < z.k_slices; ++sl) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p + sl * z.stride);
+        a[0] += c[0]; a[1] += c[1]; a[2] += c[2]; a[3] += c[3];
+    }
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+}
+template <bool SLABS>
+__global__ __launch_bounds__(1024) void k_rmsnorm(char* x, int64_t ld_x, const char* __restrict__ w, float eps,
+                                                  char* __restrict__ out, int64_t ld_out, int D, Slabs z) {
+    __shared__ float part[16];
     const int t = threadIdx.x, m = blockIdx.x;
-    const int chunks = D / 8;
-    const char* row = x + static_cast<int64_t>(m) * ld_x * 2;
-    u32x4 v[4];
+    const int pieces = D / 4;
+    char* row = x + static_cast<int64_t>(m) * ld_x * 2;
+    uint2 v[2];
     float ss = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = t + 256 * i;
-        v[i] = u32x4{0u, 0u, 0u, 0u};
-        if (c < chunks) v[i] = *reinterpret_cast<const u32x4*>(row + c * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = bf_lo(v[i][j]), b = bf_hi(v[i][j]);
-            ss = fmaf(a, a, ss);
-            ss = fmaf(b, b, ss);
+    for (int i = 0; i < 2; ++i) {
+        const int c = t + 1024 * i;
+        v[i] = uint2{0u, 0u};
+        if (c < pieces) {
+            v[i] = *reinterpret_cast<const uint2*>(row + c * 8);
+            if constexpr (SLABS) {
+                float p[4];
+                slab_sum4(z, m, c * 4, p);
+                v[i].x = pack_bf(p[0] + bf_lo(v[i].x), p[1] + bf_hi(v[i].x));
+                v[i].y = pack_bf(p[2] + bf_lo(v[i].y), p[3] + bf_hi(v[i].y));
+                *reinterpret_cast<uint2*>(row + c * 8) = v[i];
+            }
         }
+        ss = fmaf(bf_lo(v[i].x), bf_lo(v[i].x), ss);
+        ss = fmaf(bf_hi(v[i].x), bf_hi(v[i].x), ss);
+        ss = fmaf(bf_lo(v[i].y), bf_lo(v[i].y), ss);
+        ss = fmaf(bf_hi(v[i].y), bf_hi(v[i].y), ss);
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if ((t & 63) == 0) part[t >> 6] = ss;
     __syncthreads();
-    const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += part[i];
     const float inv = 1.0f / sqrtf(tot / static_cast<float>(D) + eps);
     char* orow = out + static_cast<int64_t>(m) * ld_out * 2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = t + 256 * i;
-        if (c >= chunks) continue;
-        const u32x4 wv = *reinterpret_cast<const u32x4*>(w + c * 16);
-        u32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf(bf_lo(v[i][j]) * inv * bf_lo(wv[j]), bf_hi(v[i][j]) * inv * bf_hi(wv[j]));
-        *reinterpret_cast<u32x4*>(orow + c * 16) = o;
+    for (int i = 0; i < 2; ++i) {
+        const int c = t + 1024 * i;
+        if (c >= pieces) continue;
+        const uint2 wv = *reinterpret_cast<const uint2*>(w + c * 8);
+        uint2 o;
+        o.x = pack_bf(bf_lo(v[i].x) * inv * bf_lo(wv.x), bf_hi(v[i].x) * inv * bf_hi(wv.x));
+        o.y = pack_bf(bf_lo(v[i].y) * inv * bf_lo(wv.y), bf_hi(v[i].y) * inv * bf_hi(wv.y));
+        *reinterpret_cast<uint2*>(orow + c * 8) = o;
     }
 }
 
 // ---- rotary embedding + KV-cache write.  qkv: [M][ld] = q heads | k heads | v heads of position m.  Thread = (m, head, i < 64):
 // q heads are rotated in place; k heads are rotated into k_cache[row][kvh][pos][:]; v heads go to vt_cache[row][kvh][:][pos].
 // pos[m] is clamped into the cache (padding behind a ragged feed lands in the last slot, which no real token uses).
+// SLABS: the projection's values come from the slabs (+ bias) instead of from qkv; the rotated q still goes to qkv.
+template <bool SLABS>
 __global__ __launch_bounds__(256) void k_rope_kv_store(char* __restrict__ qkv, int64_t ld, const int32_t* __restrict__ pos,
                                                        const int32_t* __restrict__ rows, const float* __restrict__ inv_freq,
                                                        char* __restrict__ k_cache, char* __restrict__ vt_cache, int M, int T,
-                                                       int H, int KVH, int t_max) {
+                                                       int H, int KVH, int t_max, Slabs z, const uint16_t* __restrict__ bias) {
     const int64_t id = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const int heads = H + 2 * KVH;
     if (id >= static_cast<int64_t>(M) * heads * 64) return;
@@ -86,7 +141,21 @@ __global__ __launch_bounds__(256) void k_rope_kv_store(char* __restrict__ qkv, i
     const int m = static_cast<int>((id >> 6) / heads);
     const int p = min(max(pos[m], 0), t_max - 1);
     uint16_t* src = reinterpret_cast<uint16_t*>(qkv + (static_cast<int64_t>(m) * ld + static_cast<int64_t>(head) * kHd) * 2);
-    const uint16_t a = src[i], b = src[i + 64];
+    uint16_t a, b;
+    if constexpr (SLABS) {
+        const int col = head * kHd + i;
+        float fa = slab_sum1(z, m, col), fb = slab_sum1(z, m, col + 64);
+        if (bias) {
+            fa += __uint_as_float(static_cast<uint32_t>(bias[col]) << 16);
+            fb += __uint_as_float(static_cast<uint32_t>(bias[col + 64]) << 16);
+        }
+        const uint32_t pr = pack_bf(fa, fb);
+        a = static_cast<uint16_t>(pr & 0xffffu);
+        b = static_cast<uint16_t>(pr >> 16);
+    } else {
+        a = src[i];
+        b = src[i + 64];
+    }
     const int seq = m / T;
     const int64_t row = rows ? rows[seq] : seq;
     if (head >= H + KVH) {                 // v: transposed store
@@ -112,15 +181,28 @@ __global__ __launch_bounds__(256) void k_rope_kv_store(char* __restrict__ qkv, i
 }
 
 // ---- act[m][i] = silu(gu[m][i]) * gu[m][I + i], f32 arithmetic, one rounding.  Thread = 8 elements.
+template <bool SLABS>
 __global__ __launch_bounds__(256) void k_silu_mul(const char* __restrict__ gu, int64_t ld_gu, char* __restrict__ act, int64_t ld_act,
-                                                  int M, int I) {
+                                                  int M, int I, Slabs z) {
     const int64_t id = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const int chunks = I / 8;
     if (id >= static_cast<int64_t>(M) * chunks) return;
     const int m = static_cast<int>(id / chunks), c = static_cast<int>(id % chunks);
-    const char* row = gu + static_cast<int64_t>(m) * ld_gu * 2;
-    const u32x4 g = *reinterpret_cast<const u32x4*>(row + c * 16);
-    const u32x4 u = *reinterpret_cast<const u32x4*>(row + (static_cast<int64_t>(I) + c * 8) * 2);
+    u32x4 g, u;
+    if constexpr (SLABS) {
+        float pg[8], pu[8];
+        slab_sum8(z, m, c * 8, pg);
+        slab_sum8(z, m, I + c * 8, pu);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g[j] = pack_bf(pg[2 * j], pg[2 * j + 1]);
+            u[j] = pack_bf(pu[2 * j], pu[2 * j + 1]);
+        }
+    } else {
+        const char* row = gu + static_cast<int64_t>(m) * ld_gu * 2;
+        g = *reinterpret_cast<const u32x4*>(row + c * 16);
+        u = *reinterpret_cast<const u32x4*>(row + (static_cast<int64_t>(I) + c * 8) * 2);
+    }
     u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -275,19 +357,45 @@ namespace {
 int check_bf16(int dtype) { return dtype == ASD_DTYPE_BF16 ? ASD_OK : ASD_ERR_UNSUPPORTED; }
 }
 
-ASD_EXPORT int asd_rmsnorm(const void* x, int64_t ld_x, const void* weight, float eps, int dtype, int M, int D, void* out,
-                           int64_t ld_out, void* stream) {
+namespace {
+Slabs slabs_of(const void* ws, int k_slices, int M, int N) {
+    Slabs z{};
+    z.base = k_slices > 1 ? static_cast<const float*>(ws) : nullptr;
+    z.k_slices = k_slices;
+    z.stride = static_cast<int64_t>(M) * N;
+    z.N = N;
+    return z;
+}
+int rmsnorm_run(void* x, int64_t ld_x, const void* weight, float eps, int dtype, int M, int D, void* out, int64_t ld_out,
+                void* stream, const Slabs& z) {
     if (M < 0 || D < 1 || !(eps >= 0.0f)) return ASD_ERR_INVALID_ARG;
     if (M == 0) return ASD_OK;
-    if (check_bf16(dtype) != ASD_OK || D % 8 != 0 || D > 8192) return ASD_ERR_UNSUPPORTED;
+    if (check_bf16(dtype) != ASD_OK || D % 4 != 0 || D > 8192) return ASD_ERR_UNSUPPORTED;
     if (!x || !weight || !out || ld_x < D || ld_out < D) return ASD_ERR_INVALID_ARG;
-    if (!aligned_to(x, 16) || !aligned_to(weight, 16) || !aligned_to(out, 16) || ld_x % 8 != 0 || ld_out % 8 != 0) return ASD_ERR_ALIGNMENT;
-    hipLaunchKernelGGL(k_rmsnorm, dim3(static_cast<unsigned>(M)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const char*>(x), ld_x, static_cast<const char*>(weight), eps, static_cast<char*>(out), ld_out, D);
+    if (!aligned_to(x, 8) || !aligned_to(weight, 8) || !aligned_to(out, 8) || ld_x % 4 != 0 || ld_out % 4 != 0) return ASD_ERR_ALIGNMENT;
+    if (z.base)
+        hipLaunchKernelGGL(k_rmsnorm<true>, dim3(static_cast<unsigned>(M)), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                           static_cast<char*>(x), ld_x, static_cast<const char*>(weight), eps, static_cast<char*>(out), ld_out, D, z);
+    else
+        hipLaunchKernelGGL(k_rmsnorm<false>, dim3(static_cast<unsigned>(M)), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                           static_cast<char*>(x), ld_x, static_cast<const char*>(weight), eps, static_cast<char*>(out), ld_out, D, z);
     return launch_status();
 }
+}  // namespace
 
+ASD_EXPORT int asd_rmsnorm(const void* x, int64_t ld_x, const void* weight, float eps, int dtype, int M, int D, void* out,
+                           int64_t ld_out, void* stream) {
+    return rmsnorm_run(const_cast<void*>(x), ld_x, weight, eps, dtype, M, D, out, ld_out, stream, Slabs{});
+}
+
+namespace {
+int silu_mul_run(const void* gate_up, int64_t ld_gu, int dtype, int M, int I, void* act, int64_t ld_act, void* stream, const Slabs& z);
+}
 ASD_EXPORT int asd_silu_mul(const void* gate_up, int64_t ld_gu, int dtype, int M, int I, void* act, int64_t ld_act, void* stream) {
+    return silu_mul_run(gate_up, ld_gu, dtype, M, I, act, ld_act, stream, Slabs{});
+}
+namespace {
+int silu_mul_run(const void* gate_up, int64_t ld_gu, int dtype, int M, int I, void* act, int64_t ld_act, void* stream, const Slabs& z) {
     if (M < 0 || I < 1) return ASD_ERR_INVALID_ARG;
     if (M == 0) return ASD_OK;
     if (check_bf16(dtype) != ASD_OK || I % 8 != 0) return ASD_ERR_UNSUPPORTED;
@@ -295,10 +403,15 @@ ASD_EXPORT int asd_silu_mul(const void* gate_up, int64_t ld_gu, int dtype, int M
     if (!aligned_to(gate_up, 16) || !aligned_to(act, 16) || ld_gu % 8 != 0 || ld_act % 8 != 0) return ASD_ERR_ALIGNMENT;
     const int64_t n = static_cast<int64_t>(M) * (I / 8);
     if ((n + 255) / 256 >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_silu_mul, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const char*>(gate_up), ld_gu, static_cast<char*>(act), ld_act, M, I);
+    if (z.base)
+        hipLaunchKernelGGL(k_silu_mul<true>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const char*>(gate_up), ld_gu, static_cast<char*>(act), ld_act, M, I, z);
+    else
+        hipLaunchKernelGGL(k_silu_mul<false>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const char*>(gate_up), ld_gu, static_cast<char*>(act), ld_act, M, I, z);
     return launch_status();
 }
+}  // namespace
 
 namespace {
 int check_attn_shape(int B, int T, int H, int KVH, int head_dim, int t_max) {
@@ -308,9 +421,18 @@ int check_attn_shape(int B, int T, int H, int KVH, int head_dim, int t_max) {
 }
 }  // namespace
 
+namespace {
+int rope_kv_run(void* qkv, int64_t ld_qkv, const int32_t* pos, const int32_t* rows, const float* inv_freq, int dtype, int B, int T,
+                int H, int KVH, int head_dim, void* k_cache, void* vt_cache, int t_max, void* stream, const Slabs& z, const void* bias);
+}
 ASD_EXPORT int asd_rope_kv_store(void* qkv, int64_t ld_qkv, const int32_t* pos, const int32_t* rows, const float* inv_freq,
                                  int dtype, int B, int T, int H, int KVH, int head_dim, void* k_cache, void* vt_cache, int t_max,
                                  void* stream) {
+    return rope_kv_run(qkv, ld_qkv, pos, rows, inv_freq, dtype, B, T, H, KVH, head_dim, k_cache, vt_cache, t_max, stream, Slabs{}, nullptr);
+}
+namespace {
+int rope_kv_run(void* qkv, int64_t ld_qkv, const int32_t* pos, const int32_t* rows, const float* inv_freq, int dtype, int B, int T,
+                int H, int KVH, int head_dim, void* k_cache, void* vt_cache, int t_max, void* stream, const Slabs& z, const void* bias) {
     if (int rc = check_attn_shape(B, T, H, KVH, head_dim, t_max)) return rc;
     if (B == 0) return ASD_OK;
     if (check_bf16(dtype) != ASD_OK) return ASD_ERR_UNSUPPORTED;
@@ -320,11 +442,17 @@ ASD_EXPORT int asd_rope_kv_store(void* qkv, int64_t ld_qkv, const int32_t* pos, 
     const int64_t M = static_cast<int64_t>(B) * T;
     const int64_t n = M * (H + 2 * KVH) * 64;
     if (M >= (1ll << 31) || (n + 255) / 256 >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_rope_kv_store, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<char*>(qkv), ld_qkv, pos, rows, inv_freq, static_cast<char*>(k_cache), static_cast<char*>(vt_cache),
-                       static_cast<int>(M), T, H, KVH, t_max);
+    if (z.base)
+        hipLaunchKernelGGL(k_rope_kv_store<true>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<char*>(qkv), ld_qkv, pos, rows, inv_freq, static_cast<char*>(k_cache), static_cast<char*>(vt_cache),
+                           static_cast<int>(M), T, H, KVH, t_max, z, static_cast<const uint16_t*>(bias));
+    else
+        hipLaunchKernelGGL(k_rope_kv_store<false>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<char*>(qkv), ld_qkv, pos, rows, inv_freq, static_cast<char*>(k_cache), static_cast<char*>(vt_cache),
+                           static_cast<int>(M), T, H, KVH, t_max, z, static_cast<const uint16_t*>(bias));
     return launch_status();
 }
+}  // namespace
 
 ASD_EXPORT int asd_attn_ragged(const void* qkv, int64_t ld_qkv, const void* k_cache, const void* vt_cache, const int32_t* pos,
                                const int32_t* rows, int dtype, int B, int T, int H, int KVH, int head_dim, int t_max,
@@ -386,16 +514,17 @@ ASD_EXPORT size_t asd_decoder_scratch_bytes(const asd_decoder_shape_t* shape, in
 }
 
 ASD_EXPORT int asd_decoder_forward(const asd_layer_t* layers, int n_layers, const asd_decoder_shape_t* shape, void* x, int64_t ld_x,
-                                   const int32_t* pos, const int32_t* rows, int B, int T, void* scratch, size_t scratch_bytes,
-                                   void* stream) {
+                                   const int32_t* pos, const int32_t* rows, int B, int T, const void* final_norm_w,
+                                   void* normed_out, int64_t ld_normed, void* scratch, size_t scratch_bytes, void* stream) {
     if (int rc = check_shape(shape)) return rc;
     if (n_layers < 0 || B < 0 || T < 1 || (n_layers > 0 && !layers)) return ASD_ERR_INVALID_ARG;
-    if (B == 0 || n_layers == 0) return ASD_OK;
+    if ((final_norm_w != nullptr) != (normed_out != nullptr)) return ASD_ERR_INVALID_ARG;
+    if (B == 0) return ASD_OK;
     const asd_decoder_shape_t& s = *shape;
     const int64_t M64 = static_cast<int64_t>(B) * T;
     if (M64 >= (1 << 24)) return ASD_ERR_UNSUPPORTED;
     const int M = static_cast<int>(M64);
-    if (!x || !pos || ld_x < s.hidden) return ASD_ERR_INVALID_ARG;
+    if (!x || !pos || ld_x < s.hidden || (normed_out && ld_normed < s.hidden)) return ASD_ERR_INVALID_ARG;
     const Scratch z = scratch_layout(s, M);
     if (!scratch || scratch_bytes < z.total) return ASD_ERR_WORKSPACE;
     if (!aligned_to(scratch, 256) || !aligned_to(x, 16) || ld_x % 8 != 0) return ASD_ERR_ALIGNMENT;
@@ -410,19 +539,40 @@ ASD_EXPORT int asd_decoder_forward(const asd_layer_t* layers, int n_layers, cons
     const int kvw = s.kv_heads * s.head_dim;
     const int qkv_w = s.hidden + 2 * kvw;
     const int dt = ASD_DTYPE_BF16;
-    for (int l = 0; l < n_layers; ++l) {
+    const int64_t gu_w = 2 * static_cast<int64_t>(s.intermediate);
+    // Where a projection's plan cuts the reduction into slices, the kernel that FOLLOWS it adds the partials itself (no reduce
+    // launch): rope + cache write after q|k|v, the next norm (with the residual connection) after o and down, silu * up after
+    // gate|up.  Nine launches per layer either way.
+    int rc = ASD_OK;
+    bool have_hn = false;              // hn already holds norm(x) for the layer about to start
+    for (int l = 0; l < n_layers && rc == ASD_OK; ++l) {
         const asd_layer_t& L = layers[l];
         if (!L.ln1_w || !L.qkv_w || !L.o_w || !L.ln2_w || !L.gate_up_w || !L.down_w || !L.k_cache || !L.vt_cache) return ASD_ERR_INVALID_ARG;
-        int rc = asd_rmsnorm(x, ld_x, L.ln1_w, s.rms_eps, dt, M, s.hidden, hn, s.hidden, stream);
-        if (rc == ASD_OK) rc = asd_linear(hn, s.hidden, L.qkv_w, s.hidden, L.qkv_b, dt, M, qkv_w, s.hidden, qkv, qkv_w, lin, lin_bytes, stream);
-        if (rc == ASD_OK) rc = asd_rope_kv_store(qkv, qkv_w, pos, rows, s.inv_freq, dt, B, T, s.heads, s.kv_heads, s.head_dim, L.k_cache, L.vt_cache, s.t_max, stream);
+        int ks = 1;
+        if (!have_hn) rc = rmsnorm_run(x, ld_x, L.ln1_w, s.rms_eps, dt, M, s.hidden, hn, s.hidden, stream, Slabs{});
+        if (rc == ASD_OK) rc = asd_linear_partial(hn, s.hidden, L.qkv_w, s.hidden, L.qkv_b, nullptr, 0, dt, M, qkv_w, s.hidden, qkv, qkv_w, lin, lin_bytes, stream, &ks);
+        if (rc == ASD_OK) rc = rope_kv_run(qkv, qkv_w, pos, rows, s.inv_freq, dt, B, T, s.heads, s.kv_heads, s.head_dim, L.k_cache, L.vt_cache, s.t_max, stream,
+                                           slabs_of(lin, ks, M, qkv_w), L.qkv_b);
         if (rc == ASD_OK) rc = asd_attn_ragged(qkv, qkv_w, L.k_cache, L.vt_cache, pos, rows, dt, B, T, s.heads, s.kv_heads, s.head_dim, s.t_max, attn, s.hidden, stream);
-        if (rc == ASD_OK) rc = asd_linear_ex(attn, s.hidden, L.o_w, s.hidden, nullptr, x, ld_x, dt, M, s.hidden, s.hidden, x, ld_x, lin, lin_bytes, stream);
-        if (rc == ASD_OK) rc = asd_rmsnorm(x, ld_x, L.ln2_w, s.rms_eps, dt, M, s.hidden, hn, s.hidden, stream);
-        if (rc == ASD_OK) rc = asd_linear(hn, s.hidden, L.gate_up_w, s.hidden, nullptr, dt, M, 2 * s.intermediate, s.hidden, gu, 2 * static_cast<int64_t>(s.intermediate), lin, lin_bytes, stream);
-        if (rc == ASD_OK) rc = asd_silu_mul(gu, 2 * static_cast<int64_t>(s.intermediate), dt, M, s.intermediate, act, s.intermediate, stream);
-        if (rc == ASD_OK) rc = asd_linear_ex(act, s.intermediate, L.down_w, s.intermediate, nullptr, x, ld_x, dt, M, s.hidden, s.intermediate, x, ld_x, lin, lin_bytes, stream);
-        if (rc != ASD_OK) return rc;
+        if (rc == ASD_OK) rc = asd_linear_partial(attn, s.hidden, L.o_w, s.hidden, nullptr, x, ld_x, dt, M, s.hidden, s.hidden, x, ld_x, lin, lin_bytes, stream, &ks);
+        if (rc == ASD_OK) rc = rmsnorm_run(x, ld_x, L.ln2_w, s.rms_eps, dt, M, s.hidden, hn, s.hidden, stream, slabs_of(lin, ks, M, s.hidden));
+        if (rc == ASD_OK) rc = asd_linear_partial(hn, s.hidden, L.gate_up_w, s.hidden, nullptr, nullptr, 0, dt, M, 2 * s.intermediate, s.hidden, gu, gu_w, lin, lin_bytes, stream, &ks);
+        if (rc == ASD_OK) rc = silu_mul_run(gu, gu_w, dt, M, s.intermediate, act, s.intermediate, stream, slabs_of(lin, ks, M, 2 * s.intermediate));
+        if (rc == ASD_OK) rc = asd_linear_partial(act, s.intermediate, L.down_w, s.intermediate, nullptr, x, ld_x, dt, M, s.hidden, s.intermediate, x, ld_x, lin, lin_bytes, stream, &ks);
+        if (rc != ASD_OK) break;
+        // the norm that follows the down projection: the next layer's ln1, or the final norm
+        const bool last = l + 1 == n_layers;
+        const void* next_w = last ? final_norm_w : layers[l + 1].ln1_w;
+        void* next_out = last ? normed_out : hn;
+        const int64_t next_ld = last ? ld_normed : s.hidden;
+        if (next_w) {
+            rc = rmsnorm_run(x, ld_x, next_w, s.rms_eps, dt, M, s.hidden, next_out, next_ld, stream, slabs_of(lin, ks, M, s.hidden));
+            have_hn = true;
+        } else if (ks > 1) {           // no norm follows: finish the residual connection on its own
+            rc = rmsnorm_run(x, ld_x, L.ln2_w, s.rms_eps, dt, M, s.hidden, hn, s.hidden, stream, slabs_of(lin, ks, M, s.hidden));
+        }
     }
-    return ASD_OK;
+    if (rc == ASD_OK && n_layers == 0 && final_norm_w)
+        rc = rmsnorm_run(x, ld_x, final_norm_w, s.rms_eps, dt, M, s.hidden, normed_out, ld_normed, stream, Slabs{});
+    return rc;
 }

@@ -1427,9 +1427,13 @@ ASD_EXPORT int asd_debug_force_linear_slices(int k) {      // 0: the plan's own 
     return old;
 }
 
-ASD_EXPORT int asd_linear_ex(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, const void* residual,
-                             int64_t ld_res, int dtype, int M, int N, int D, void* y, int64_t ld_y, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+namespace {
+// k_slices_out != NULL: a sliced plan stops after the product -- the f32 partials stay in `workspace` as [k_slices][M][N]
+// and the caller's own kernel adds them (bias and residual are then the caller's too); an unsliced plan stores y as usual.
+int linear_run(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, const void* residual,
+               int64_t ld_res, int dtype, int M, int N, int D, void* y, int64_t ld_y, void* workspace,
+               size_t workspace_bytes, void* stream, int* k_slices_out) {
+    if (k_slices_out) *k_slices_out = 1;
     if (M < 0 || N < 1 || D < 1) return ASD_ERR_INVALID_ARG;
     if (residual && (ld_res < N || ld_res % 4 != 0 || !aligned_to(residual, 8))) return ld_res < N ? ASD_ERR_INVALID_ARG : ASD_ERR_ALIGNMENT;
     if (M == 0) return ASD_OK;
@@ -1466,13 +1470,28 @@ ASD_EXPORT int asd_linear_ex(const void* x, int64_t ld_x, const void* w, int64_t
         if (f16) hipLaunchKernelGGL((k_lm_head_quad<true, true>), grid, dim3(kQThreads), 0, st, p);
         else hipLaunchKernelGGL((k_lm_head_quad<false, true>), grid, dim3(kQThreads), 0, st, p);
     }
-    if (pl.k_slices > 1) {
+    if (k_slices_out) *k_slices_out = pl.k_slices;
+    if (pl.k_slices > 1 && !k_slices_out) {
         const int64_t n_threads = static_cast<int64_t>(M) * (N / 4);
         const dim3 rgrid(static_cast<unsigned>((n_threads + 255) / 256));
         if (f16) hipLaunchKernelGGL(k_linear_reduce<true>, rgrid, dim3(256), 0, st, p.slabs, pl.k_slices, M, N, bias, residual, ld_res, y, ld_y);
         else hipLaunchKernelGGL(k_linear_reduce<false>, rgrid, dim3(256), 0, st, p.slabs, pl.k_slices, M, N, bias, residual, ld_res, y, ld_y);
     }
     return launch_status();
+}
+}  // namespace
+
+ASD_EXPORT int asd_linear_ex(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, const void* residual,
+                             int64_t ld_res, int dtype, int M, int N, int D, void* y, int64_t ld_y, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    return linear_run(x, ld_x, w, ld_w, bias, residual, ld_res, dtype, M, N, D, y, ld_y, workspace, workspace_bytes, stream, nullptr);
+}
+
+ASD_EXPORT int asd_linear_partial(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, const void* residual,
+                                  int64_t ld_res, int dtype, int M, int N, int D, void* y, int64_t ld_y, void* workspace,
+                                  size_t workspace_bytes, void* stream, int* k_slices) {
+    if (!k_slices) return ASD_ERR_INVALID_ARG;
+    return linear_run(x, ld_x, w, ld_w, bias, residual, ld_res, dtype, M, N, D, y, ld_y, workspace, workspace_bytes, stream, k_slices);
 }
 
 ASD_EXPORT int asd_linear(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, int dtype, int M, int N,

@@ -90,14 +90,12 @@ class HipDecoder:
         rows32 = None if rows is None else rows.to(torch.int32).contiguous()
         scratch = self._scratch_for(M)
         base = (scratch.data_ptr() + 255) // 256 * 256
-        rc = self.lib.asd_decoder_forward(self._layers, s.layers, C.byref(self._shape), x.data_ptr(), x.stride(0), pos.data_ptr(),
-                                          None if rows32 is None else rows32.data_ptr(), Bn, T, base,
-                                          scratch.numel() - (base - scratch.data_ptr()), K._stream())
-        B.check("asd_decoder_forward", rc)
         hn = torch.empty_like(x)
-        rc = self.lib.asd_rmsnorm(x.data_ptr(), x.stride(0), lm.norm.weight.data_ptr(), float(s.rms_eps), B.DTYPE_BF16, M, s.hidden,
-                                  hn.data_ptr(), hn.stride(0), K._stream())
-        B.check("asd_rmsnorm", rc)
+        rc = self.lib.asd_decoder_forward(self._layers, s.layers, C.byref(self._shape), x.data_ptr(), x.stride(0), pos.data_ptr(),
+                                          None if rows32 is None else rows32.data_ptr(), Bn, T, lm.norm.weight.data_ptr(),
+                                          hn.data_ptr(), hn.stride(0), base, scratch.numel() - (base - scratch.data_ptr()),
+                                          K._stream())
+        B.check("asd_decoder_forward", rc)
         if return_hidden:
             return hn.view(Bn, T, s.hidden)
         logits = K.linear(hn, lm.lm_head.weight, workspace=self._lin_ws)

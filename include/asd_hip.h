@@ -204,6 +204,13 @@ int asd_linear(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const v
 int asd_linear_ex(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, const void* residual,
                   int64_t ld_res, int dtype, int M, int N, int D, void* y /*[M][ld_y] out*/, int64_t ld_y, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* Building block of asd_decoder_forward: as asd_linear_ex, but a plan with reduction slices stops after the product --
+ * *k_slices > 1 on return means y was NOT written: the f32 partials lie in `workspace` as [k_slices][M][N] and the caller's
+ * next kernel adds them in slice order, then the bias, then the residual (the order asd_linear_ex uses: same bits).
+ * *k_slices == 1: y is complete. */
+int asd_linear_partial(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, const void* residual,
+                       int64_t ld_res, int dtype, int M, int N, int D, void* y, int64_t ld_y, void* workspace,
+                       size_t workspace_bytes, void* stream, int* k_slices /*out*/);
 /* test hooks: the reduction slices the launcher would use; force a count (0 = the launcher's own choice; process-wide) */
 int asd_debug_linear_slices(int M, int N, int D);
 int asd_debug_force_linear_slices(int k_slices);   /* returns the previous value */
@@ -211,7 +218,7 @@ int asd_debug_force_linear_slices(int k_slices);   /* returns the previous value
 /* ------------------------------------------------------------------------------------------
  * X2, continued: the rest of a decoder layer around the projections, for the M = B * T positions a tier is fed in one pass
  * (row m = b * T + t), over a per-sequence KV cache.  bf16 only; head_dim 128 (every Qwen2.5 shape).
- *   asd_rmsnorm        out = x * rsqrt(mean(x^2) + eps) * weight, f32 arithmetic, one rounding; D % 8 == 0, D <= 8192
+ *   asd_rmsnorm        out = x * rsqrt(mean(x^2) + eps) * weight, f32 arithmetic, one rounding; D % 4 == 0, D <= 8192
  *   asd_rope_kv_store  qkv [M][ld] = q heads | k heads | v heads: rotary embedding (half-split pairs (i, i + 64), angle
  *                      pos[m] * inv_freq[i]) of q IN PLACE and of k INTO the cache; v into the TRANSPOSED cache
  *                        k_cache  [cache rows][KVH][t_max][128]      vt_cache [cache rows][KVH][128][t_max]
@@ -252,9 +259,13 @@ int asd_attn_ragged(const void* qkv, int64_t ld_qkv, const void* k_cache, const 
 int asd_silu_mul(const void* gate_up /*[M][ld_gu], 2 I wide*/, int64_t ld_gu, int dtype, int M, int I, void* act /*[M][ld_act]*/,
                  int64_t ld_act, void* stream);
 size_t asd_decoder_scratch_bytes(const asd_decoder_shape_t* shape, int M);
+/* final_norm_w / normed_out (both or neither): the model's last RMSNorm, applied to the final x into normed_out [B*T][ld_normed]
+ * (fused with the last layer's residual connection).  Where a projection is cut into reduction slices, the kernel that follows
+ * it adds the slices' partials itself (asd_linear_partial), so a layer is nine launches whatever the plans are. */
 int asd_decoder_forward(const asd_layer_t* layers, int n_layers, const asd_decoder_shape_t* shape, void* x /*[B*T][ld_x] in/out*/,
-                        int64_t ld_x, const int32_t* pos, const int32_t* rows, int B, int T, void* scratch /*256-byte aligned*/,
-                        size_t scratch_bytes, void* stream);
+                        int64_t ld_x, const int32_t* pos, const int32_t* rows, int B, int T, const void* final_norm_w,
+                        void* normed_out, int64_t ld_normed, void* scratch /*256-byte aligned*/, size_t scratch_bytes,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * N3  commit / KV rollback bookkeeping of one token-level step, on the device.

@@ -191,6 +191,51 @@ def test_hip_decoder_matches_torch_modules_and_fp32():
         assert eh <= max(2.0 * et, 0.02 * scale), (eh, et, scale)
 
 
+def test_decoder_forward_equals_the_composition_of_its_parts():
+    """asd_decoder_forward lets the kernel after a sliced projection add the f32 partials itself; the exported parts, called
+    one by one with asd_linear_ex's own reduce kernel in between, must give the same bits."""
+    SL = import_module("adaptive-speculative-decoding_amd.serving.synthetic_lm")
+    K_ = import_module("adaptive-speculative-decoding_amd.kernels")
+    lib, Bd = _lib(), _B()
+    shape = _small_shape()
+    lm = SL.SyntheticLM(shape, dtype=BF, device="cuda", seed=6)
+    lm.enable_hip_layers()
+    Bn, T, t_max = 3, 5, 64
+    lm.alloc_ragged(Bn, t_max)
+    hd = lm._hip
+    g = _gen(2)
+    ids = torch.randint(0, shape.vocab, (Bn, T), generator=g, device="cuda")
+    pos0 = torch.tensor([0, 7, 30], device="cuda")
+    # the composition, on its own caches
+    M = Bn * T
+    x = lm.embed(ids).view(M, shape.hidden).clone()
+    pos = (pos0[:, None] + torch.arange(T, device="cuda")).reshape(M).to(torch.int32)
+    ws = K_.LinearWorkspace("cuda")
+    kv = shape.kv_heads * 128
+    for i, blk in enumerate(lm.blocks):
+        qkv_w, qkv_b, gu_w = hd._fused[i]
+        kc, vt = torch.zeros_like(hd.k_cache[i]), torch.zeros_like(hd.vt_cache[i])
+        hn = torch.empty_like(x)
+        _check(lib.asd_rmsnorm(x.data_ptr(), shape.hidden, blk.ln1.weight.data_ptr(), shape.rms_eps, Bd.DTYPE_BF16, M, shape.hidden, hn.data_ptr(), shape.hidden, None), "asd_rmsnorm")
+        qkv = K_.linear(hn, qkv_w, qkv_b, workspace=ws)
+        _check(lib.asd_rope_kv_store(qkv.data_ptr(), qkv.stride(0), pos.data_ptr(), None, hd.inv_freq.data_ptr(), Bd.DTYPE_BF16, Bn, T,
+                                     shape.heads, shape.kv_heads, 128, kc.data_ptr(), vt.data_ptr(), hd.t_max, None), "asd_rope_kv_store")
+        attn = torch.empty(M, shape.hidden, dtype=BF, device="cuda")
+        _check(lib.asd_attn_ragged(qkv.data_ptr(), qkv.stride(0), kc.data_ptr(), vt.data_ptr(), pos.data_ptr(), None, Bd.DTYPE_BF16, Bn, T,
+                                   shape.heads, shape.kv_heads, 128, hd.t_max, attn.data_ptr(), shape.hidden, None), "asd_attn_ragged")
+        K_.linear(attn, blk.o.weight, workspace=ws, out=x, residual=x)
+        _check(lib.asd_rmsnorm(x.data_ptr(), shape.hidden, blk.ln2.weight.data_ptr(), shape.rms_eps, Bd.DTYPE_BF16, M, shape.hidden, hn.data_ptr(), shape.hidden, None), "asd_rmsnorm")
+        gu = K_.linear(hn, gu_w, workspace=ws)
+        act = torch.empty(M, shape.intermediate, dtype=BF, device="cuda")
+        _check(lib.asd_silu_mul(gu.data_ptr(), gu.stride(0), Bd.DTYPE_BF16, M, shape.intermediate, act.data_ptr(), shape.intermediate, None), "asd_silu_mul")
+        K_.linear(act, blk.down.weight, workspace=ws, out=x, residual=x)
+    want = torch.empty_like(x)
+    _check(lib.asd_rmsnorm(x.data_ptr(), shape.hidden, lm.norm.weight.data_ptr(), shape.rms_eps, Bd.DTYPE_BF16, M, shape.hidden, want.data_ptr(), shape.hidden, None), "asd_rmsnorm")
+    got = lm.forward_ragged(ids, pos0, 40, return_hidden=True)
+    assert lib.asd_debug_linear_slices(M, shape.hidden, shape.hidden) > 1           # the fused consumers really ran
+    assert torch.equal(got.view(M, shape.hidden), want)
+
+
 def test_hip_decoder_graph_replay_equals_eager():
     SL = import_module("adaptive-speculative-decoding_amd.serving.synthetic_lm")
     shape = _small_shape()
@@ -218,3 +263,62 @@ def test_hip_decoder_refuses_cpu_and_other_head_dims():
         SL.SyntheticLM(SL.tiny(), device="cpu").enable_hip_layers()
     with pytest.raises(RuntimeError):
         SL.SyntheticLM(SL.tiny(), device="cuda").enable_hip_layers()                  # head_dim 32
+
+
+def test_three_tier_loop_with_hip_decoder_models():
+    """The stop-or-escalate loop with every tier's passes going through asd_decoder_forward: accept masks against the oracle on
+    the recorded logits (bit-exact outside the stated margin), committed lengths, and -- the KV-rollback check -- the logits of
+    the stateful model against a from-scratch pass of a fresh model over each sequence's committed context."""
+    import numpy as np
+    from oracle import oracle as O
+    from asd_amd.distributed import HipOps
+    from asd_amd.serving import hierarchy as H
+    from tests.test_hierarchy import _predictor
+    SL = import_module("adaptive-speculative-decoding_amd.serving.synthetic_lm")
+    V, Bn, P, NEW, Kd = 1000, 6, 5, 24, 4
+    shape = SL.LMShape("small", 512, 2, 4, 2, 1024, vocab=V, rope_theta=1.0e6)
+    prompt = torch.randint(0, V, (Bn, P), generator=torch.Generator().manual_seed(7)).cuda()
+    cfg = H.HierarchyConfig(draft_len=Kd, temperature=0.7, top_p=0.9, lambda_value=25.0, seed=3)
+    pl = H.Placement.for_world(1)
+    kw = dict(heads=("logits", "logits"), logit_scale=4.0, keep_inputs=True, weight_noise=(0.0, 0.02, 0.04), share_seed=1)
+    draft, tiers = H.build_rank_roles(0, pl, [shape] * 3, cfg, prompt, NEW, _predictor(), ops=HipOps(), hip_layers=True, **kw)
+    assert draft.m.execution == "hip_decoder" and all(t.m.execution == "hip_decoder" for t in tiers.values())
+    tr = H.generate_hierarchical(draft, [tiers[1], tiers[2]], keep_inputs=True)
+    assert (tr.seq_len == P + NEW).all()
+    assert tr.tier_calls[1] > 0
+    fresh = SL.SyntheticLM(shape, dtype=BF, device="cuda", seed=1, logit_scale=4.0)
+    fresh.lm_head.weight.data.copy_(tiers[1].m.lm_head.weight.data)
+    fresh.enable_hip_layers()
+    inv_t = np.float32(1 / 0.7)
+    lens = np.full(Bn, P)
+    buf = np.zeros((Bn, P + NEW), np.int32)
+    buf[:, :P] = prompt.cpu().numpy()
+    checked, compared = 0, 0
+    for rec in tr.records:
+        dm, final = rec["draft"], rec["final"]
+        if 1 in rec["tiers"]:
+            v, _ = rec["tiers"][1]
+            idx = v.idx.cpu().numpy()
+            inp, n = v.inputs, len(idx)
+            tok, lp_d, u = (inp[k].cpu().numpy() for k in ("tok", "lp_d", "u"))
+            store = inp["logits"].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+            ref = O.verify_accept(store.reshape(n * Kd, V), O.DT_BF16, tok, lp_d, u, n, Kd, V, inv_temperature=inv_t)
+            safe = ref["margin"] >= 1e-4
+            assert np.array_equal(v.accept.cpu().numpy()[safe], ref["accept"][safe])
+            checked += int(safe.sum())
+            for i, b in enumerate(idx[:2]):                      # from-scratch pass over the committed context + the draft
+                ctx = np.concatenate([buf[b, :lens[b]], tok[i]])
+                fresh.alloc_ragged(1, 64)
+                full = fresh.forward_ragged(torch.from_numpy(ctx[None, :]).to(torch.int64).cuda(), torch.zeros(1, dtype=torch.int64, device="cuda"), len(ctx))[0]
+                got = inp["logits"][i].float()
+                want = full[lens[b] - 1: lens[b] - 1 + Kd].float()
+                # same weights, same kernels, but other row counts per call (other slice plans, other MFMA tilings): bf16 noise
+                assert (got - want).abs().max().item() <= 0.05 * want.abs().max().item()
+                compared += 1
+        tokc = dm.tok.cpu().numpy()
+        for b in range(Bn):
+            new = (list(tokc[b, :int(final.n_acc[b])]) + [int(final.drawn[b])])[: max(0, P + NEW - lens[b])]
+            buf[b, lens[b]:lens[b] + len(new)] = new
+            lens[b] += len(new)
+    assert np.array_equal(buf, tr.tokens.cpu().numpy())
+    assert checked > 50 and compared > 4
