@@ -1,4 +1,4 @@
-// decoder.hip -- X2 (the callers' side of the path): one pass of a Qwen2.5-shape decoder stack over the M = B * T
+// decoder.hip -- X3 (the callers' side of the path): one pass of a Qwen2.5-shape decoder stack over the M = B * T
 // positions the token-level loop feeds a tier, with a per-sequence (ragged) KV cache.  The reference delegates this to
 // transformers / vLLM (src/serving/real_model_pipeline.py:135, src/models/stage.py); in the bench's loop it was ~1500 torch
 // launches per pass of the 7B shape (15.5 ms even replayed from a hipGraph, 6.4 ms of them GEMMs).  Here a layer is NINE launches:

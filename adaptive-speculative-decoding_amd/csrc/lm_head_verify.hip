@@ -1350,13 +1350,15 @@ ASD_EXPORT int asd_lm_head_pack_weights(const void* weight, int64_t ld_w, int dt
 
 // ---------------------------------------------------------------------------------------------------------------------
 // asd_linear: y[M][N] = x[M][D] . w[N][D]^T (+ bias) -- the projections of the decoder layers around the path (the callers'
-// side), on the SAME three kernels with the STORE epilogue:
+// side, X3), on the SAME three kernels with the STORE epilogue:
 //   M <= 64    k_lm_head_skinny (stream-shaped: the call is HBM-bound)     column blocks x reduction slices
-//   M <= 256   k_lm_head_tile<4> (8 waves, 256 x 256)                       column blocks x reduction slices
-//   M  > 256   k_lm_head_quad (4 waves x 128 x 128, row blocks share a weight tile through the XCD's L2)
+//   M  > 64    k_linear_tile (8 waves; 256-row blocks as 4 x 2 waves, a last block of <= 128 / <= 64 rows as 2 x 4 / 1 x 8)
+//              row blocks x column blocks x reduction slices
+//   M  > 256 and an unsliced grid of >= 2 x CUs:  k_lm_head_quad (4 waves x 128 x 128, the MFMA-bound form)
 // A layer's matrices are narrow (N = 3584 .. 57344: 14 .. 224 column blocks of 256) next to the lm_head's 594, so the
 // reduction is cut into slices until the grid fills the CUs; the slices write f32 partials ([slice][M][N], L2 / MALL
-// resident) and k_linear_reduce adds them in slice order (bit-reproducible), adds the bias and rounds once.
+// resident) and k_linear_reduce -- or, inside asd_decoder_forward, the kernel that consumes the product (asd_linear_partial) --
+// adds them in slice order (bit-reproducible), adds bias and residual and rounds once.
 namespace {
 struct LinearPlan {
     int kind;        // 0 skinny, 1 tile, 2 quad

@@ -283,7 +283,7 @@ class LinearWorkspace:
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, workspace: LinearWorkspace,
            out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """X2: y = x @ weight.T (+ bias) (+ residual) through asd_linear_ex.  x [..., D], weight [N, D] (nn.Linear layout), all bf16
+    """X3: y = x @ weight.T (+ bias) (+ residual) through asd_linear_ex.  x [..., D], weight [N, D] (nn.Linear layout), all bf16
     or all f16 CUDA tensors; returns [..., N] of the same type.  residual [M, N] may be `out` itself (in-place accumulate)."""
     if weight.dim() != 2 or weight.dtype not in (torch.bfloat16, torch.float16) or not weight.is_cuda or weight.stride(1) != 1:
         raise ValueError("weight must be a [N, D] bf16 or f16 CUDA tensor with contiguous rows")

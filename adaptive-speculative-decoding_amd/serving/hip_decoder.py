@@ -1,4 +1,4 @@
-"""X2: the decoder stack of a SyntheticLM through asd_decoder_forward (csrc/decoder.hip + asd_linear) instead of torch modules.
+"""X3: the decoder stack of a SyntheticLM through asd_decoder_forward (csrc/decoder.hip + asd_linear) instead of torch modules.
 
 The reference runs its tiers through transformers / vLLM (third party: src/serving/real_model_pipeline.py:135); the bench's
 token-level loop needs SOME model execution around the path, and with torch modules a pass of the 7B shape was ~1500 launches.

@@ -202,7 +202,7 @@ class SyntheticLM(nn.Module):
         self._max_graphs = int(max_graphs)
 
     def enable_hip_layers(self, on: bool = True) -> None:
-        """Run forward_ragged through asd_decoder_forward (X2: csrc/decoder.hip + asd_linear; nine launches per layer, one host
+        """Run forward_ragged through asd_decoder_forward (X3: csrc/decoder.hip + asd_linear; nine launches per layer, one host
         call per pass) instead of the torch modules.  CUDA + bf16 + head_dim 128 only; raises otherwise -- no fallback.  Call
         before alloc_ragged.  The lock-step `forward` / `truncate` cache keeps the torch modules."""
         if on:

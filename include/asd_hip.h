@@ -189,7 +189,7 @@ int asd_lm_head_partial(const void* hidden, int64_t ld_h, const void* weight_sha
                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * X2 (callers' side of the path)  y[M][N] = x[M][D] . w[N][D]^T (+ bias[N]): the nn.Linear projections of the
+ * X3 (callers' side of the path)  y[M][N] = x[M][D] . w[N][D]^T (+ bias[N]): the nn.Linear projections of the
  * decoder layers the reference runs through transformers / vLLM (third party there: src/serving/real_model_pipeline.py:135,
  * src/models/stage.py) -- the step that produces the hidden states asd_lm_head_verify consumes and, for the draft tier, the
  * logits asd_draft_sample consumes.  The lm_head kernels' main loops with a STORE epilogue; narrow matrices are cut into
@@ -216,7 +216,7 @@ int asd_debug_linear_slices(int M, int N, int D);
 int asd_debug_force_linear_slices(int k_slices);   /* returns the previous value */
 
 /* ------------------------------------------------------------------------------------------
- * X2, continued: the rest of a decoder layer around the projections, for the M = B * T positions a tier is fed in one pass
+ * X3, continued: the rest of a decoder layer around the projections, for the M = B * T positions a tier is fed in one pass
  * (row m = b * T + t), over a per-sequence KV cache.  bf16 only; head_dim 128 (every Qwen2.5 shape).
  *   asd_rmsnorm        out = x * rsqrt(mean(x^2) + eps) * weight, f32 arithmetic, one rounding; D % 4 == 0, D <= 8192
  *   asd_rope_kv_store  qkv [M][ld] = q heads | k heads | v heads: rotary embedding (half-split pairs (i, i + 64), angle

@@ -1,4 +1,4 @@
-"""X2: the decoder-layer kernels (csrc/decoder.hip) and the HipDecoder stack against plain PyTorch fp32 references of the
+"""X3: the decoder-layer kernels (csrc/decoder.hip) and the HipDecoder stack against plain PyTorch fp32 references of the
 same ops on the same bf16 inputs.  Floating point: tolerances are stated per test (one bf16 rounding of the result = 2^-9
 relative, plus the arithmetic differences named there)."""
 import math

@@ -1,4 +1,4 @@
-"""X2: asd_linear (y = x . w^T + bias through the lm_head kernels' main loops with a STORE epilogue) against an f64 product of
+"""X3: asd_linear (y = x . w^T + bias through the lm_head kernels' main loops with a STORE epilogue) against an f64 product of
 the same bf16 / f16 operands.  Floating point: the kernel accumulates in f32 (MFMA order) and rounds ONCE to the operand
 type, so the bound is half an output ulp (2^-9 relative for bf16, 2^-12 for f16) plus the f32 accumulation error -- written
 below as  |y - ref| <= 2^-8 |ref| + 2e-4  (bf16)  /  2^-11 |ref| + 2e-4  (f16)."""

@@ -1,4 +1,4 @@
-"""X2: asd_linear beside torch's F.linear (hipBLASLt / rocBLAS) on the decoder-layer projections of the Qwen2.5 shapes at the
+"""X3: asd_linear beside torch's F.linear (hipBLASLt / rocBLAS) on the decoder-layer projections of the Qwen2.5 shapes at the
 row counts of the token-level loop: M = 32 (draft, one token per sequence), 208 / 288 (verify tiers, K + 1 positions).
 Weights rotate over enough copies to exceed the 256 MB MALL, so the figures are HBM figures.
     python tools/bench_linear.py [--out gpurun_out/linear.json] [--models 7b,32b,72b] [--rows 32,288]"""
