@@ -356,7 +356,7 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
                  "frac": loop_bytes / elapsed / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": loop_bytes / max(1, tr.steps),
                  "floor_ms_per_step_at_8TBs": 1e3 * loop_bytes / max(1, tr.steps) / 8e12, "per_tier": per_tier,
                  "what": "bytes of every model pass (weights once per pass + K/V attended + logits written and re-read) / step time; "
-                         "model execution is torch plumbing (third party in the reference), the hot-path kernels are `hot_path_calls`"}
+                         "model execution (third party in the reference): see `model_execution` -- the HIP decoder stack of DESIGN 4.9 or torch modules; the hot-path kernels are `hot_path_calls`"}
     rec = {
         "tiers": [s.name for s in shp], "placement": {"draft": pl.draft, "tiers": pl.tiers, "ranks": world},
         "heads": list(heads), "batch": B, "draft_len": K, "prompt_len": prompt_len, "steps": tr.steps, "warmup": warmup,

@@ -322,3 +322,42 @@ def test_three_tier_loop_with_hip_decoder_models():
             lens[b] += len(new)
     assert np.array_equal(buf, tr.tokens.cpu().numpy())
     assert checked > 50 and compared > 4
+
+
+def test_decoder_entry_points_reject_bad_arguments():
+    lib, Bd = _lib(), _B()
+    x = torch.zeros(4, 256, dtype=BF, device="cuda")
+    w = torch.ones(256, dtype=BF, device="cuda")
+    out = torch.empty_like(x)
+    ok = lib.asd_rmsnorm(x.data_ptr(), 256, w.data_ptr(), 1e-6, Bd.DTYPE_BF16, 4, 256, out.data_ptr(), 256, None)
+    assert ok == 0
+    assert lib.asd_rmsnorm(x.data_ptr(), 256, w.data_ptr(), 1e-6, Bd.DTYPE_F16, 4, 256, out.data_ptr(), 256, None) < 0       # bf16 only
+    assert lib.asd_rmsnorm(x.data_ptr(), 128, w.data_ptr(), 1e-6, Bd.DTYPE_BF16, 4, 256, out.data_ptr(), 256, None) < 0      # ld < D
+    assert lib.asd_rmsnorm(None, 256, w.data_ptr(), 1e-6, Bd.DTYPE_BF16, 4, 256, out.data_ptr(), 256, None) < 0
+    assert lib.asd_rmsnorm(x.data_ptr(), 256, w.data_ptr(), 1e-6, Bd.DTYPE_BF16, 4, 16384, out.data_ptr(), 16384, None) < 0   # D > 8192
+    assert lib.asd_rmsnorm(x.data_ptr(), 256, w.data_ptr(), 1e-6, Bd.DTYPE_BF16, 0, 256, out.data_ptr(), 256, None) == 0      # nothing to do
+    kc = torch.zeros(1, 1, 32, 128, dtype=BF, device="cuda")
+    vt = torch.zeros(1, 1, 128, 32, dtype=BF, device="cuda")
+    qkv = torch.zeros(1, 3 * 128, dtype=BF, device="cuda")
+    pos = torch.zeros(1, dtype=torch.int32, device="cuda")
+    args = (qkv.data_ptr(), 384, kc.data_ptr(), vt.data_ptr(), pos.data_ptr(), None, Bd.DTYPE_BF16, 1, 1, 1, 1)
+    o = torch.zeros(1, 128, dtype=BF, device="cuda")
+    assert lib.asd_attn_ragged(*args, 128, 32, o.data_ptr(), 128, None) == 0
+    assert lib.asd_attn_ragged(*args, 64, 32, o.data_ptr(), 128, None) < 0          # head_dim 64
+    assert lib.asd_attn_ragged(*args, 128, 40, o.data_ptr(), 128, None) < 0         # t_max % 32
+    assert lib.asd_attn_ragged(*args, 128, 32, o.data_ptr(), 64, None) < 0          # ld_out < H * 128
+    import ctypes as C
+    shp = Bd.DecoderShape(256, 2, 1, 128, 512, 1e-6, None, 32)
+    assert lib.asd_decoder_scratch_bytes(C.byref(shp), 4) == 0                       # inv_freq missing
+    inv = torch.ones(64, device="cuda")
+    shp = Bd.DecoderShape(256, 2, 1, 128, 512, 1e-6, inv.data_ptr(), 32)
+    need = lib.asd_decoder_scratch_bytes(C.byref(shp), 4)
+    assert need > 0
+    sc = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    base = (sc.data_ptr() + 255) // 256 * 256
+    x4 = torch.zeros(4, 256, dtype=BF, device="cuda")
+    p4 = torch.zeros(4, dtype=torch.int32, device="cuda")
+    assert lib.asd_decoder_forward(None, 0, C.byref(shp), x4.data_ptr(), 256, p4.data_ptr(), None, 4, 1, None, None, 0, base, need, None) == 0
+    assert lib.asd_decoder_forward(None, 1, C.byref(shp), x4.data_ptr(), 256, p4.data_ptr(), None, 4, 1, None, None, 0, base, need, None) < 0   # layers missing
+    assert lib.asd_decoder_forward(None, 0, C.byref(shp), x4.data_ptr(), 256, p4.data_ptr(), None, 4, 1, w.data_ptr(), None, 0, base, need, None) < 0  # norm without out
+    assert lib.asd_decoder_forward(None, 0, C.byref(shp), x4.data_ptr(), 256, p4.data_ptr(), None, 4, 1, None, None, 0, base, 16, None) < 0        # scratch too small
