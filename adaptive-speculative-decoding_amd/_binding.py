@@ -70,6 +70,7 @@ SIGNATURES = {
     "asd_decoder_scratch_bytes": (_sz, [_vp, _i]),
     "asd_decoder_forward": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "asd_debug_force_linear_slices": (_i, [_i]),
+    "asd_debug_linear_tall": (_i, [_i]),
     "asd_lm_head_partial": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
     "asd_commit_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),
     "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),

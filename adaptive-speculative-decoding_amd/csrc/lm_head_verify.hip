@@ -224,14 +224,18 @@ __device__ __forceinline__ void fold_tile16(const f32x16& a, int n_first, int tk
 // <= 128 rows and 1 x 8 waves over one of <= 64 rows, so that a short LAST row block -- M = 288 = 256 + 32, the K + 1 = 9
 // positions of 32 sequences -- costs its share of MFMAs instead of a full block's).  A wave always owns 64 rows x 32 * NTW
 // columns; the block is 32 * NTW * (8 / WM) columns wide.
-template <int NTW, int HPASSES, bool F16, bool STORE, int WM>
+// MT: 32-row accumulator tiles per wave (2 everywhere but the "tall" STORE form: 1 x 8 waves of 9 x 1 tiles = ONE row block
+// of 288 rows x 256 columns -- the K + 1 = 9 positions of 32 sequences without a second, mostly empty row block; its hidden
+// slot is 320 rows, so the weight ring is WRING = 2 slots: one superstage in flight, which its 2.5 us of MFMAs per superstage hide).
+template <int NTW, int HPASSES, bool F16, bool STORE, int WM, int MT = 2, int WRING = kWRing>
 __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* const lds) {
     constexpr int WN = 8 / WM;               // wave columns
     constexpr int BN = 32 * NTW * WN;
     constexpr int kWSlot = BN * 128;         // one weight superstage
-    constexpr int kHSlot = kBM * 128;        // one hidden superstage
+    constexpr int kRowBlock = WM * MT * 32 > kBM ? WM * MT * 32 : kBM;        // rows a workgroup owns
+    constexpr int kHSlot = (64 * HPASSES > kBM ? 64 * HPASSES : kBM) * 128;   // one hidden superstage
     constexpr int WPASSES = BN / 64;         // DMA instructions per thread and superstage (64 rows per pass)
-    unsigned char* const lds_h = lds + kWRing * kWSlot;
+    unsigned char* const lds_h = lds + WRING * kWSlot;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wv = t >> 6;
@@ -261,9 +265,9 @@ __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* 
         }
     }
     const int n0 = p.col0 + nb * BN;
-    const int m0 = mb * kBM;
+    const int m0 = mb * kRowBlock;
     const int rows_w = min(BN, p.V - n0);
-    const int rows_h = min(kBM, p.M - m0);
+    const int rows_h = min(kRowBlock, p.M - m0);
 
     // DMA sources: one instruction moves 8 rows x 128 B (lane -> row lane >> 3, 16-byte segment lane & 7,
     // swizzled).  Rows past a matrix edge re-read the last valid row (their products are masked in the
@@ -301,7 +305,7 @@ __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* 
     auto issue_w = [&](int stage) {
         const char* src = wbase + static_cast<int64_t>(stage) * w_stage_stride;
         asm volatile("" : "+s"(src));   // keep the base in SGPRs: without it LLVM folds the lane offset into a 64-bit VGPR pointer
-        unsigned char* dst = lds + (stage % kWRing) * kWSlot + wv_s * 1024;
+        unsigned char* dst = lds + (stage % WRING) * kWSlot + wv_s * 1024;
 #pragma unroll
         for (int ps = 0; ps < WPASSES; ++ps)
             __builtin_amdgcn_global_load_lds((glb_void*)(src + woff[ps]), (lds_void*)(dst + ps * 8192), 16, 0, 2);
@@ -315,31 +319,31 @@ __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* 
             __builtin_amdgcn_global_load_lds((glb_void*)(src + hoff[ps]), (lds_void*)(dst + ps * 8192), 16, 0, 0);
     };
 
-    f32x16 acc[2][NTW];
+    f32x16 acc[MT][NTW];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
 
     // wave-uniform: a wave whose rows or columns are all padding only stages
-    const bool wave_works = 64 * wm < rows_h && 32 * NTW * wn < rows_w;
+    const bool wave_works = 32 * MT * wm < rows_h && 32 * NTW * wn < rows_w;
     const int key = (r >> 1) & 7;
-    const int h_off = (64 * wm + r) * 128;
+    const int h_off = (32 * MT * wm + r) * 128;
     const int w_off = (32 * NTW * wn + r) * 128;
     // The fragment reads of k-step ks + 1 are issued before the MFMAs of k-step ks (two register sets; the
     // sched_barriers pin that order -- left alone the scheduler emits read, read, wait, mfma, mfma).  The LAST
     // k-step of a superstage is multiplied only after the next barrier: its fragments are in registers by
     // then, so the MFMA pipe has work while the wave issues the DMA of the coming superstages and waits for
     // the first fragments of the next one (the barrier -> first MFMA bubble was ~12 % of an iteration).
-    bf16x8 wf[2][NTW], hf[2][2];
+    bf16x8 wf[2][NTW], hf[2][MT];
     auto read_frags = [&](int S, int ks, int set) {
-        const unsigned char* wb = lds + (S % kWRing) * kWSlot + w_off;
+        const unsigned char* wb = lds + (S % WRING) * kWSlot + w_off;
         const unsigned char* hb = lds_h + (S & (kHRing - 1)) * kHSlot + h_off;
         const int so = ((4 * h + ks) ^ key) * 16;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) hf[set][mt] = *reinterpret_cast<const bf16x8*>(hb + mt * 32 * 128 + so);
+        for (int mt = 0; mt < MT; ++mt) hf[set][mt] = *reinterpret_cast<const bf16x8*>(hb + mt * 32 * 128 + so);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) wf[set][nt] = *reinterpret_cast<const bf16x8*>(wb + nt * 32 * 128 + so);
     };
@@ -347,7 +351,7 @@ __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);   // MFMA issue ahead of the other wave's reads / DMA issue: -10 % (7B head)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
                 acc[mt][nt] = mfma32<F16>(wf[set][nt], hf[set][mt], acc[mt][nt]);
@@ -359,15 +363,15 @@ __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* 
     auto multiply_interleaved = [&](int set) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
                 acc[mt][nt] = mfma32<F16>(wf[set][nt], hf[set][mt], acc[mt][nt]);
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-        for (int i = 0; i < 2 * NTW; ++i) {
+        for (int i = 0; i < MT * NTW; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 2 + NTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i < MT + NTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -398,6 +402,19 @@ __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* 
     // The slots refilled after it (hidden: slot of S-1; weights: slot (S+2) % 3 = (S-1) % 3) were read into
     // registers -- k-step 3 included, see wait_and_meet's lgkmcnt(0) -- before their readers reached it.
     int S = s_begin;
+    if constexpr (WRING == 2) {
+        // two weight slots: W(S + 1) and H(S + 1) go out behind the barrier that opens superstage S (their slots held S - 1,
+        // whose readers passed that barrier) and must have landed at the next one: vmcnt(0)
+        if (S < n_super) { issue_w(S); issue_h(S); }
+        for (; S < n_super; ++S) {
+            wait_and_meet<0>();
+            if (S > s_begin) tail();
+            const bool more = S + 1 < n_super;
+            if (more && wn < WN / 2) { issue_h(S + 1); issue_w(S + 1); }       // (the two waves of a SIMD issue at different points)
+            head(S, [&] { if (more && wn >= WN / 2) { issue_h(S + 1); issue_w(S + 1); } });
+        }
+        if (n_super > s_begin) tail();
+    } else {
 #if ASD_LMHEAD_LAB & 1
     // lab, "math alone": no load in the loop, so EVERY ring slot is filled once with real operands up front (round 3: with one
     // weight slot and one hidden slot left as whatever the previous kernel had in LDS the variant's time depended on that
@@ -448,6 +465,7 @@ __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* 
     if (n_super > s_begin) tail();   // k-step 3 of the last superstage
 #endif
 
+    }
     // ---- reduction slices: every slice publishes its partial accumulators; the one that draws the last
     // ticket adds the others' and goes on to the epilogue.  Hand-off: plain 16-byte stores, every wave drains
     // them (vmcnt), workgroup barrier, ONE agent-scope release + ticket by lane 0; the finisher acquires once,
@@ -521,10 +539,10 @@ __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* 
     if constexpr (STORE) {
         if (wave_works) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
-                    store_tile16<F16>(acc[mt][nt], m0 + 64 * wm + 32 * mt + r, n0 + 32 * NTW * wn + 32 * nt + 4 * h, slice, p);
+                    store_tile16<F16>(acc[mt][nt], m0 + 32 * MT * wm + 32 * mt + r, n0 + 32 * NTW * wn + 32 * nt + 4 * h, slice, p);
         }
         return;
     }
@@ -605,6 +623,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_linear_tile(LmHeadParams p) {
     if (rows_h > 128) tile_body<4, 4, F16, true, 4>(p, lds);
     else if (rows_h > 64) tile_body<2, 2, F16, true, 2>(p, lds);
     else tile_body<1, 1, F16, true, 1>(p, lds);
+}
+
+// asd_linear, 256 < M <= 288: ONE row block of 288 rows, 1 x 8 waves of 9 x 1 tiles (see tile_body's MT)
+template <bool F16>
+__global__ __launch_bounds__(kThreads, 1) void k_linear_tall(LmHeadParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 256 * 128 + kHRing * 320 * 128];
+    tile_body<1, 5, F16, true, 1, 9, 2>(p, lds);
 }
 
 // ---- M > 256 rows (several row blocks share every weight tile): FOUR waves per workgroup, 128 x 128 logits per wave.
@@ -1360,8 +1385,9 @@ ASD_EXPORT int asd_lm_head_pack_weights(const void* weight, int64_t ld_w, int dt
 // resident) and k_linear_reduce -- or, inside asd_decoder_forward, the kernel that consumes the product (asd_linear_partial) --
 // adds them in slice order (bit-reproducible), adds bias and residual and rounds once.
 namespace {
+int g_linear_tall = 1;     // asd_debug_linear_tall(0): 256 < M <= 288 as 256 + 32 rows (A/B measurements)
 struct LinearPlan {
-    int kind;        // 0 skinny, 1 tile, 2 quad
+    int kind;        // 0 skinny, 1 tile, 2 quad, 3 tall (one 288-row block)
     int k_slices;
     int64_t units;   // workgroups before slicing
 };
@@ -1376,6 +1402,10 @@ LinearPlan linear_plan(int M, int N, int D) {
     pl.kind = M <= kSkRows ? 0 : ((m_blocks >= 2 && blocks * m_blocks >= 2 * cus) ? 2 : 1);
     pl.units = blocks * m_blocks;
     pl.k_slices = 1;
+    if (M > kBM && M <= 288 && g_linear_tall) {       // one 288-row block per column block
+        pl.kind = 3;
+        pl.units = blocks;
+    }
     // cost of a plan in superstages per CU: rounds x (superstages of a slice + pipeline fill) (+ the slab round trip)
     const int total = D / kSuper;
     // Cost of a plan in superstage-times of one CU.  A workgroup of a sliced launch pays its share of the reduction, the
@@ -1384,10 +1414,10 @@ LinearPlan linear_plan(int M, int N, int D) {
     // Makespan: whole rounds of the FULL workgroups (a CU holds one), or the total work spread over the CUs if that is
     // more; a last row block of <= 64 / <= 128 rows counts as a quarter / half of a workgroup.
     const int fill = 3;
-    const int rows_eff = M < kBM ? M : kBM;
+    const int rows_eff = pl.kind == 3 ? 288 : (M < kBM ? M : kBM);
     const int slab = (rows_eff + 15) / 16;
     int64_t full_units = pl.units, rem_units = 0, rem_quarters = 0;
-    if (pl.kind != 0) {
+    if (pl.kind == 1 || pl.kind == 2) {
         const int rem = M - static_cast<int>(m_blocks - 1) * kBM;
         if (rem <= 128) {
             full_units = blocks * (m_blocks - 1);
@@ -1423,6 +1453,11 @@ ASD_EXPORT int asd_debug_linear_slices(int M, int N, int D) {      // the plan's
 namespace {
 int g_force_linear_slices = 0;
 }
+ASD_EXPORT int asd_debug_linear_tall(int on) {            // returns the previous value
+    const int old = g_linear_tall;
+    g_linear_tall = on ? 1 : 0;
+    return old;
+}
 ASD_EXPORT int asd_debug_force_linear_slices(int k) {      // 0: the plan's own choice; returns the previous value
     const int old = g_force_linear_slices;
     g_force_linear_slices = k < 0 ? 0 : k;
@@ -1455,7 +1490,7 @@ int linear_run(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const v
     LmHeadParams p{};
     p.hidden = x; p.ld_h = ld_x; p.weight = w; p.ld_w = ld_w;
     p.D = D; p.M = M; p.V = N;
-    p.m_blocks = (M + kBM - 1) / kBM;
+    p.m_blocks = pl.kind == 3 ? 1 : (M + kBM - 1) / kBM;
     p.n_blocks = (N + 255) / 256;
     p.k_slices = pl.k_slices;
     p.slabs = static_cast<float*>(workspace);
@@ -1468,6 +1503,9 @@ int linear_run(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const v
     } else if (pl.kind == 1) {
         if (f16) hipLaunchKernelGGL(k_linear_tile<true>, grid, dim3(kThreads), 0, st, p);
         else hipLaunchKernelGGL(k_linear_tile<false>, grid, dim3(kThreads), 0, st, p);
+    } else if (pl.kind == 3) {
+        if (f16) hipLaunchKernelGGL(k_linear_tall<true>, grid, dim3(kThreads), 0, st, p);
+        else hipLaunchKernelGGL(k_linear_tall<false>, grid, dim3(kThreads), 0, st, p);
     } else {
         if (f16) hipLaunchKernelGGL((k_lm_head_quad<true, true>), grid, dim3(kQThreads), 0, st, p);
         else hipLaunchKernelGGL((k_lm_head_quad<false, true>), grid, dim3(kQThreads), 0, st, p);

@@ -214,6 +214,7 @@ int asd_linear_partial(const void* x, int64_t ld_x, const void* w, int64_t ld_w,
 /* test hooks: the reduction slices the launcher would use; force a count (0 = the launcher's own choice; process-wide) */
 int asd_debug_linear_slices(int M, int N, int D);
 int asd_debug_force_linear_slices(int k_slices);   /* returns the previous value */
+int asd_debug_linear_tall(int on);                 /* 256 < M <= 288 as one 288-row block (1, default) or as 256 + 32 rows (0) */
 
 /* ------------------------------------------------------------------------------------------
  * X3, continued: the rest of a decoder layer around the projections, for the M = B * T positions a tier is fed in one pass

@@ -45,9 +45,11 @@ def main():
     ap.add_argument("--models", default="7b,32b,72b")
     ap.add_argument("--rows", default="32,288")
     ap.add_argument("--force-slices", type=int, default=0)
+    ap.add_argument("--no-tall", action="store_true", help="256 < M <= 288 as 256 + 32 rows instead of one 288-row block")
     a = ap.parse_args()
     lib = K_._lib()
     lib.asd_debug_force_linear_slices(a.force_slices)
+    lib.asd_debug_linear_tall(0 if a.no_tall else 1)
     ws = K_.LinearWorkspace("cuda")
     res = []
     for name in a.models.split(","):
