@@ -42,13 +42,6 @@ struct Slabs {
     int64_t stride;        // M * N
     int N;
 };
-__device__ __forceinline__ float slab_sum1(const Slabs& z, int m, int n) {
-    const float* p = z.base + static_cast<int64_t>(m) * z.N + n;
-    float acc = p[0];
-#pragma unroll 4
-    for (int sl = 1; sl < z.k_slices; ++sl) acc += p[sl * z.stride];     // (unrolled: the loads go out together, the adds keep slice order)
-    return acc;
-}
 __device__ __forceinline__ void slab_sum8(const Slabs& z, int m, int n, float (&v)[8]) {
     const float* p = z.base + static_cast<int64_t>(m) * z.N + n;
     f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -124,7 +117,7 @@ __global__ __launch_bounds__(1024) void k_rmsnorm(char* x, int64_t ld_x, const c
     }
 }
 
-// ---- rotary embedding + KV-cache write.  qkv: [M][ld] = q heads | k heads | v heads of position m.  Thread = (m, head, i < 64):
+// ---- rotary embedding + KV-cache write.  qkv: [M][ld] = q heads | k heads | v heads of position m.  Pairs (i, i + 64), i < 64:
 // q heads are rotated in place; k heads are rotated into k_cache[row][kvh][pos][:]; v heads go to vt_cache[row][kvh][:][pos].
 // pos[m] is clamped into the cache (padding behind a ragged feed lands in the last slot, which no real token uses).
 // SLABS: the projection's values come from the slabs (+ bias) instead of from qkv; the rotated q still goes to qkv.
@@ -133,51 +126,66 @@ __global__ __launch_bounds__(256) void k_rope_kv_store(char* __restrict__ qkv, i
                                                        const int32_t* __restrict__ rows, const float* __restrict__ inv_freq,
                                                        char* __restrict__ k_cache, char* __restrict__ vt_cache, int M, int T,
                                                        int H, int KVH, int t_max, Slabs z, const uint16_t* __restrict__ bias) {
+    // thread = (position m, head, four pairs i = 4 i4 .. 4 i4 + 3 with their partners i + 64): 16-byte slab loads, 8-byte stores
     const int64_t id = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const int heads = H + 2 * KVH;
-    if (id >= static_cast<int64_t>(M) * heads * 64) return;
-    const int i = static_cast<int>(id & 63);
-    const int head = static_cast<int>((id >> 6) % heads);
-    const int m = static_cast<int>((id >> 6) / heads);
+    if (id >= static_cast<int64_t>(M) * heads * 16) return;
+    const int i0 = static_cast<int>(id & 15) * 4;
+    const int head = static_cast<int>((id >> 4) % heads);
+    const int m = static_cast<int>((id >> 4) / heads);
     const int p = min(max(pos[m], 0), t_max - 1);
-    uint16_t* src = reinterpret_cast<uint16_t*>(qkv + (static_cast<int64_t>(m) * ld + static_cast<int64_t>(head) * kHd) * 2);
-    uint16_t a, b;
+    char* const src = qkv + (static_cast<int64_t>(m) * ld + static_cast<int64_t>(head) * kHd) * 2;
+    float x1[4], x2[4];                 // the projection's values, already rounded to bf16
     if constexpr (SLABS) {
-        const int col = head * kHd + i;
-        float fa = slab_sum1(z, m, col), fb = slab_sum1(z, m, col + 64);
-        if (bias) {
-            fa += __uint_as_float(static_cast<uint32_t>(bias[col]) << 16);
-            fb += __uint_as_float(static_cast<uint32_t>(bias[col + 64]) << 16);
+        const int col = head * kHd + i0;
+        slab_sum4(z, m, col, x1);
+        slab_sum4(z, m, col + 64, x2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (bias) {
+                x1[j] += __uint_as_float(static_cast<uint32_t>(bias[col + j]) << 16);
+                x2[j] += __uint_as_float(static_cast<uint32_t>(bias[col + 64 + j]) << 16);
+            }
+            const uint32_t pr = pack_bf(x1[j], x2[j]);
+            x1[j] = bf_lo(pr);
+            x2[j] = bf_hi(pr);
         }
-        const uint32_t pr = pack_bf(fa, fb);
-        a = static_cast<uint16_t>(pr & 0xffffu);
-        b = static_cast<uint16_t>(pr >> 16);
     } else {
-        a = src[i];
-        b = src[i + 64];
+        const uint2 a = *reinterpret_cast<const uint2*>(src + i0 * 2), b = *reinterpret_cast<const uint2*>(src + (i0 + 64) * 2);
+        x1[0] = bf_lo(a.x); x1[1] = bf_hi(a.x); x1[2] = bf_lo(a.y); x1[3] = bf_hi(a.y);
+        x2[0] = bf_lo(b.x); x2[1] = bf_hi(b.x); x2[2] = bf_lo(b.y); x2[3] = bf_hi(b.y);
     }
     const int seq = m / T;
     const int64_t row = rows ? rows[seq] : seq;
-    if (head >= H + KVH) {                 // v: transposed store
+    if (head >= H + KVH) {                 // v: transposed store (the values are bf16 already: pack_bf is exact on them)
         const int kvh = head - H - KVH;
         uint16_t* dst = reinterpret_cast<uint16_t*>(vt_cache) + ((row * KVH + kvh) * kHd) * static_cast<int64_t>(t_max) + p;
-        dst[static_cast<int64_t>(i) * t_max] = a;
-        dst[static_cast<int64_t>(i + 64) * t_max] = b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dst[static_cast<int64_t>(i0 + j) * t_max] = static_cast<uint16_t>(__float_as_uint(x1[j]) >> 16);
+            dst[static_cast<int64_t>(i0 + j + 64) * t_max] = static_cast<uint16_t>(__float_as_uint(x2[j]) >> 16);
+        }
         return;
     }
-    const float x1 = __uint_as_float(static_cast<uint32_t>(a) << 16), x2 = __uint_as_float(static_cast<uint32_t>(b) << 16);
-    const float ang = static_cast<float>(p) * inv_freq[i];
-    const float c = cosf(ang), s = sinf(ang);
-    const uint32_t o = pack_bf(x1 * c - x2 * s, x2 * c + x1 * s);
-    if (head < H) {
-        src[i] = static_cast<uint16_t>(o & 0xffffu);
-        src[i + 64] = static_cast<uint16_t>(o >> 16);
-    } else {
-        const int kvh = head - H;
-        uint16_t* dst = reinterpret_cast<uint16_t*>(k_cache) + (((row * KVH + kvh) * static_cast<int64_t>(t_max)) + p) * kHd;
-        dst[i] = static_cast<uint16_t>(o & 0xffffu);
-        dst[i + 64] = static_cast<uint16_t>(o >> 16);
+    float o1[4], o2[4];
+    const f32x4 fr = *reinterpret_cast<const f32x4*>(inv_freq + i0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float ang = static_cast<float>(p) * fr[j];
+        const float c = cosf(ang), sn = sinf(ang);
+        o1[j] = x1[j] * c - x2[j] * sn;
+        o2[j] = x2[j] * c + x1[j] * sn;
     }
+    uint2 lo, hi;
+    lo.x = pack_bf(o1[0], o1[1]); lo.y = pack_bf(o1[2], o1[3]);
+    hi.x = pack_bf(o2[0], o2[1]); hi.y = pack_bf(o2[2], o2[3]);
+    char* dst = src;
+    if (head >= H) {
+        const int kvh = head - H;
+        dst = k_cache + ((((row * KVH + kvh) * static_cast<int64_t>(t_max)) + p) * kHd) * 2;
+    }
+    *reinterpret_cast<uint2*>(dst + i0 * 2) = lo;
+    *reinterpret_cast<uint2*>(dst + (i0 + 64) * 2) = hi;
 }
 
 // ---- act[m][i] = silu(gu[m][i]) * gu[m][I + i], f32 arithmetic, one rounding.  Thread = 8 elements.
@@ -440,7 +448,7 @@ int rope_kv_run(void* qkv, int64_t ld_qkv, const int32_t* pos, const int32_t* ro
     if (!qkv || !pos || !inv_freq || !k_cache || !vt_cache || ld_qkv < width) return ASD_ERR_INVALID_ARG;
     if (!aligned_to(qkv, 16) || !aligned_to(k_cache, 16) || !aligned_to(vt_cache, 16) || ld_qkv % 8 != 0) return ASD_ERR_ALIGNMENT;
     const int64_t M = static_cast<int64_t>(B) * T;
-    const int64_t n = M * (H + 2 * KVH) * 64;
+    const int64_t n = M * (H + 2 * KVH) * 16;
     if (M >= (1ll << 31) || (n + 255) / 256 >= (1ll << 31)) return ASD_ERR_UNSUPPORTED;
     if (z.base)
         hipLaunchKernelGGL(k_rope_kv_store<true>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
