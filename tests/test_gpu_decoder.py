@@ -77,14 +77,16 @@ def test_rope_kv_store(Bn, T, H, KVH, subset):
     width = (H + 2 * KVH) * 128
     qkv = torch.randn(M, width, generator=g, device="cuda").to(BF)
     pos0 = torch.randint(0, t_max - T, (Bn,), generator=g, device="cuda")
-    pos = (pos0[:, None] + torch.arange(T, device="cuda")).reshape(M).to(torch.int32)
+    pos0[-1] = t_max - 1                                            # its later positions fall off the cache: clamped to t_max - 1
+    pos_raw = (pos0[:, None] + torch.arange(T, device="cuda")).reshape(M).to(torch.int32)
+    pos = pos_raw.clamp(max=t_max - 1)
     Bc = Bn + 2
     rows = torch.tensor([Bc - 1 - i for i in range(Bn)], dtype=torch.int32, device="cuda") if subset else None
     kc = torch.zeros(Bc, KVH, t_max, 128, dtype=BF, device="cuda")
     vt = torch.zeros(Bc, KVH, 128, t_max, dtype=BF, device="cuda")
     inv = (1.0 / (theta ** (torch.arange(0, 128, 2, device="cuda", dtype=torch.float32) / 128))).contiguous()
     orig = qkv.clone()
-    _check(_lib().asd_rope_kv_store(qkv.data_ptr(), width, pos.data_ptr(), None if rows is None else rows.data_ptr(), inv.data_ptr(),
+    _check(_lib().asd_rope_kv_store(qkv.data_ptr(), width, pos_raw.data_ptr(), None if rows is None else rows.data_ptr(), inv.data_ptr(),
                                     _B().DTYPE_BF16, Bn, T, H, KVH, 128, kc.data_ptr(), vt.data_ptr(), t_max, None), "asd_rope_kv_store")
     o = orig.double().view(M, H + 2 * KVH, 128)
     q_ref = _rope_ref(o[:, :H], pos, theta)
@@ -97,6 +99,8 @@ def test_rope_kv_store(Bn, T, H, KVH, subset):
         b = m // T
         row = int(rows[b]) if subset else b
         p = int(pos[m])
+        if T > 1 and b == Bn - 1:
+            continue                       # several positions of this feed share the last slot: which one it keeps is not defined
         assert bool(((kc[row, :, p].double() - k_ref[m]).abs() <= 2.0 ** -8 * k_ref[m].abs() + 1e-5).all())
         assert torch.equal(vt[row, :, :, p], orig.view(M, H + 2 * KVH, 128)[m, H + KVH:])
     written = torch.zeros(Bc, t_max, dtype=torch.bool, device="cuda")

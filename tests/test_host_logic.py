@@ -538,3 +538,14 @@ def test_a14_features_from_device_statistics_equal_the_host_extractor():
     dev = FeatureExtractor.extract_device(mx, en, [4] * B, [3] * B, 3, n_valid=torch.tensor(n_valid))
     np.testing.assert_allclose(dev.numpy(), host, atol=2e-6, rtol=0)
     assert dev.shape == (B, 256) and dev[3, 3] == -10.0 and dev[3, 0] == 0.0
+
+
+def test_hip_decoder_has_no_cpu_form():
+    """X3: the HIP decoder stack refuses a CPU model (and the torch modules stay what a CPU model runs)."""
+    import pytest
+    from asd_amd.serving.synthetic_lm import SyntheticLM, tiny
+    lm = SyntheticLM(tiny(), device="cpu")
+    assert lm.execution == "torch_modules"
+    with pytest.raises(RuntimeError):
+        lm.enable_hip_layers()
+    assert lm.execution == "torch_modules"
