@@ -1425,13 +1425,19 @@ LinearPlan linear_plan(int M, int N, int D) {
             rem_quarters = rem <= 64 ? 1 : 2;
         }
     }
+    // (measured, tools/sweep_linear_slices.py -> profiles/r03_linear_slices_*.json: while the partials stay in the 256 MB MALL
+    // beside the weight stream their round trip costs a quarter of that; and whoever adds them walks the slices one after the
+    // other -- 0.45 us, three quarters of a superstage-time, per slice)
     double best = -1.0;
     for (int sl = 1; sl <= 32 && sl <= total; ++sl) {
-        const double t_unit = static_cast<double>((total + sl - 1) / sl + fill + (sl > 1 ? slab : 0));
+        const double slab_bytes = static_cast<double>(sl) * M * static_cast<double>(N) * 4.0;
+        const double slab_cost = sl > 1 ? (slab_bytes > 128.0e6 ? slab : (slab >= 4 ? slab / 4.0 : 1.0)) : 0.0;
+        const double t_unit = static_cast<double>((total + sl - 1) / sl + fill) + slab_cost;
         const double by_rounds = static_cast<double>((full_units * sl + cus - 1) / cus) * t_unit;
         const double by_work = (static_cast<double>(full_units) + 0.25 * rem_quarters * static_cast<double>(rem_units)) * sl * t_unit / cus;
         double cost = by_rounds > by_work ? by_rounds : by_work;
         if (full_units == 0) cost = static_cast<double>((rem_units * sl + cus - 1) / cus) * t_unit;   // one short row block only
+        if (sl > 1) cost += 0.75 * sl;
         if (best < 0.0 || cost < best) { best = cost; pl.k_slices = sl; }
     }
     return pl;
