@@ -75,3 +75,21 @@ def test_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "libasd_oracle" not in text, f
+
+
+def test_linear_plan_is_sane_without_a_gpu():
+    """X3: the reduction-slice plan of asd_linear is host arithmetic (a device with no visible GPU counts as 256 CUs): at least
+    one slice, never more than the reduction has superstages, none for a grid that already fills the CUs, and a workspace
+    that holds exactly the plan's partials."""
+    import ctypes as C
+    from asd_amd import _binding as B
+    lib = B.load_library()
+    for (M, N, D) in [(1, 3584, 3584), (32, 3584, 3584), (32, 152064, 3584), (64, 512, 64), (99, 8192, 29568), (207, 59136, 8192),
+                      (288, 5120, 27648), (288, 55296, 5120), (992, 3584, 3584), (1024, 152064, 8192)]:
+        k = lib.asd_debug_linear_slices(M, N, D)
+        assert 1 <= k <= min(32, D // 64), (M, N, D, k)
+        need = lib.asd_linear_workspace_bytes(M, N, D)
+        assert need >= (k * M * N * 4 if k > 1 else 0) and need <= k * M * N * 4 + 1024
+    assert lib.asd_debug_linear_slices(32, 59136, 8192) == 1            # 231 column blocks on 256 CUs: one round, no slicing
+    assert lib.asd_debug_linear_slices(32, 3584, 3584) > 1              # 14 column blocks
+    assert lib.asd_debug_linear_slices(32, 3584, 100) == 0 and lib.asd_linear_workspace_bytes(32, 3584, 100) == 0   # D % 64

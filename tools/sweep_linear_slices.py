@@ -21,15 +21,18 @@ def main():
     ap.add_argument("--rows", default="32")
     ap.add_argument("--slices", default="1,2,3,4,5,6,7,8,10,12,14,16,18,20,24,28,32")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None, help="comma-separated matrix names (qkv, o, gate_up, down, lm_head)")
     a = ap.parse_args()
     lib = K_._lib()
     ws = K_.LinearWorkspace("cuda")
     s = SL.QWEN25_SHAPES[a.model]
     kv = s.kv_heads * s.head_dim
     mats = {"qkv": (s.hidden + 2 * kv, s.hidden), "o": (s.hidden, s.hidden), "gate_up": (2 * s.intermediate, s.hidden),
-            "down": (s.hidden, s.intermediate)}
+            "down": (s.hidden, s.intermediate), "lm_head": (s.vocab, s.hidden)}
     res = []
     for mname, (N, D) in mats.items():
+        if a.only and mname not in a.only.split(","):
+            continue
         wbytes = N * D * 2
         n_rot = max(2, min(8, (600 << 20) // wbytes + 1))
         W = [torch.randn(N, D, device="cuda", dtype=torch.bfloat16) * D ** -0.5 for _ in range(n_rot)]
