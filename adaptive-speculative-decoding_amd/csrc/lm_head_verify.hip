@@ -626,10 +626,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_linear_tile(LmHeadParams p) {
 }
 
 // asd_linear, 256 < M <= 288: ONE row block of 288 rows, 1 x 8 waves of 9 x 1 tiles (see tile_body's MT)
-template <bool F16>
+template <bool F16, int MT>
 __global__ __launch_bounds__(kThreads, 1) void k_linear_tall(LmHeadParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 256 * 128 + kHRing * 320 * 128];
-    tile_body<1, 5, F16, true, 1, 9, 2>(p, lds);
+    tile_body<1, (32 * MT + 63) / 64, F16, true, 1, MT, 2>(p, lds);
 }
 
 // ---- M > 256 rows (several row blocks share every weight tile): FOUR waves per workgroup, 128 x 128 logits per wave.
@@ -1402,7 +1402,7 @@ LinearPlan linear_plan(int M, int N, int D) {
     pl.kind = M <= kSkRows ? 0 : ((m_blocks >= 2 && blocks * m_blocks >= 2 * cus) ? 2 : 1);
     pl.units = blocks * m_blocks;
     pl.k_slices = 1;
-    if (M > kBM && M <= 288 && g_linear_tall) {       // one 288-row block per column block
+    if ((M > kBM && M <= 288 && g_linear_tall) || (M > 192 && M <= kBM && g_linear_tall >= 2)) {   // one 224 / 256 / 288-row block per column block
         pl.kind = 3;
         pl.units = blocks;
     }
@@ -1414,7 +1414,7 @@ LinearPlan linear_plan(int M, int N, int D) {
     // Makespan: whole rounds of the FULL workgroups (a CU holds one), or the total work spread over the CUs if that is
     // more; a last row block of <= 64 / <= 128 rows counts as a quarter / half of a workgroup.
     const int fill = 3;
-    const int rows_eff = pl.kind == 3 ? 288 : (M < kBM ? M : kBM);
+    const int rows_eff = pl.kind == 3 ? (M + 31) / 32 * 32 : (M < kBM ? M : kBM);
     const int slab = (rows_eff + 15) / 16;
     int64_t full_units = pl.units, rem_units = 0, rem_quarters = 0;
     if (pl.kind == 1 || pl.kind == 2) {
@@ -1429,7 +1429,10 @@ LinearPlan linear_plan(int M, int N, int D) {
     // beside the weight stream their round trip costs a quarter of that; and whoever adds them walks the slices one after the
     // other -- 0.45 us, three quarters of a superstage-time, per slice)
     double best = -1.0;
-    for (int sl = 1; sl <= 32 && sl <= total; ++sl) {
+    // (stream-shaped kernel with more than half a round of column blocks: unsliced -- forced counts measured level or worse
+    // there, even counts 8-15 % worse: gate|up at M = 32, profiles/r03_linear_slices_*.json)
+    const int max_slices = (pl.kind == 0 && pl.units * 2 > cus) ? 1 : 32;
+    for (int sl = 1; sl <= max_slices && sl <= total; ++sl) {
         const double slab_bytes = static_cast<double>(sl) * M * static_cast<double>(N) * 4.0;
         const double slab_cost = sl > 1 ? (slab_bytes > 128.0e6 ? slab : (slab >= 4 ? slab / 4.0 : 1.0)) : 0.0;
         const double t_unit = static_cast<double>((total + sl - 1) / sl + fill) + slab_cost;
@@ -1437,6 +1440,13 @@ LinearPlan linear_plan(int M, int N, int D) {
         const double by_work = (static_cast<double>(full_units) + 0.25 * rem_quarters * static_cast<double>(rem_units)) * sl * t_unit / cus;
         double cost = by_rounds > by_work ? by_rounds : by_work;
         if (full_units == 0) cost = static_cast<double>((rem_units * sl + cus - 1) / cus) * t_unit;   // one short row block only
+        if (pl.kind == 0) {
+            // the stream-shaped kernel is HBM-bound: a partial last round is not a whole round (its workgroups share the
+            // bandwidth the idle CUs leave) -- the lm_head's 594 blocks run 2.3, not 3, rounds; only the fill is per round
+            const double wgs = static_cast<double>(pl.units) * sl;
+            const double share = wgs > static_cast<double>(cus) ? wgs / static_cast<double>(cus) : 1.0;
+            cost = share * static_cast<double>((total + sl - 1) / sl) + static_cast<double>((pl.units * sl + cus - 1) / cus) * (fill + slab_cost);
+        }
         if (sl > 1) cost += 0.75 * sl;
         if (best < 0.0 || cost < best) { best = cost; pl.k_slices = sl; }
     }
@@ -1461,7 +1471,7 @@ int g_force_linear_slices = 0;
 }
 ASD_EXPORT int asd_debug_linear_tall(int on) {            // returns the previous value
     const int old = g_linear_tall;
-    g_linear_tall = on ? 1 : 0;
+    g_linear_tall = on < 0 ? 0 : (on > 2 ? 2 : on);
     return old;
 }
 ASD_EXPORT int asd_debug_force_linear_slices(int k) {      // 0: the plan's own choice; returns the previous value
@@ -1510,8 +1520,16 @@ int linear_run(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const v
         if (f16) hipLaunchKernelGGL(k_linear_tile<true>, grid, dim3(kThreads), 0, st, p);
         else hipLaunchKernelGGL(k_linear_tile<false>, grid, dim3(kThreads), 0, st, p);
     } else if (pl.kind == 3) {
-        if (f16) hipLaunchKernelGGL(k_linear_tall<true>, grid, dim3(kThreads), 0, st, p);
-        else hipLaunchKernelGGL(k_linear_tall<false>, grid, dim3(kThreads), 0, st, p);
+        const int mt = (M + 31) / 32;
+        if (f16) {
+            if (mt <= 7) hipLaunchKernelGGL((k_linear_tall<true, 7>), grid, dim3(kThreads), 0, st, p);
+            else if (mt == 8) hipLaunchKernelGGL((k_linear_tall<true, 8>), grid, dim3(kThreads), 0, st, p);
+            else hipLaunchKernelGGL((k_linear_tall<true, 9>), grid, dim3(kThreads), 0, st, p);
+        } else {
+            if (mt <= 7) hipLaunchKernelGGL((k_linear_tall<false, 7>), grid, dim3(kThreads), 0, st, p);
+            else if (mt == 8) hipLaunchKernelGGL((k_linear_tall<false, 8>), grid, dim3(kThreads), 0, st, p);
+            else hipLaunchKernelGGL((k_linear_tall<false, 9>), grid, dim3(kThreads), 0, st, p);
+        }
     } else {
         if (f16) hipLaunchKernelGGL((k_lm_head_quad<true, true>), grid, dim3(kQThreads), 0, st, p);
         else hipLaunchKernelGGL((k_lm_head_quad<false, true>), grid, dim3(kQThreads), 0, st, p);

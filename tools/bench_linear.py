@@ -46,10 +46,15 @@ def main():
     ap.add_argument("--rows", default="32,288")
     ap.add_argument("--force-slices", type=int, default=0)
     ap.add_argument("--no-tall", action="store_true", help="256 < M <= 288 as 256 + 32 rows instead of one 288-row block")
+    ap.add_argument("--tall-mode", type=int, default=None, help="asd_debug_linear_tall: 0 off, 1 for 256 < M <= 288, 2 also for 192 < M <= 256")
+    ap.add_argument("--no-torch", action="store_true")
     a = ap.parse_args()
     lib = K_._lib()
     lib.asd_debug_force_linear_slices(a.force_slices)
-    lib.asd_debug_linear_tall(0 if a.no_tall else 1)
+    if a.tall_mode is not None:
+        lib.asd_debug_linear_tall(a.tall_mode)
+    elif a.no_tall:
+        lib.asd_debug_linear_tall(0)
     ws = K_.LinearWorkspace("cuda")
     res = []
     for name in a.models.split(","):
@@ -65,7 +70,7 @@ def main():
                 x = torch.randn(M, D, device="cuda", dtype=torch.bfloat16)
                 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
                 t_asd = time_us(lambda i: K_.linear(x, W[i], workspace=ws, out=out), n_rot)
-                t_torch = time_us(lambda i: F.linear(x, W[i]), n_rot)
+                t_torch = float("nan") if a.no_torch else time_us(lambda i: F.linear(x, W[i]), n_rot)
                 r = {"model": name, "matrix": mname, "M": M, "N": N, "D": D, "slices": int(lib.asd_debug_linear_slices(M, N, D)),
                      "asd_us": round(t_asd, 2), "torch_us": round(t_torch, 2), "asd_TBps": round(wbytes / t_asd / 1e6, 3),
                      "torch_TBps": round(wbytes / t_torch / 1e6, 3), "asd_TFLOPs": round(2.0 * M * N * D / t_asd / 1e6, 1)}
