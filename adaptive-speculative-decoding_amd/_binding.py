@@ -102,7 +102,7 @@ def verify_options(inv_temperature: float = 1.0, splits: int = 0, threads: int =
 class Layer(C.Structure):
     """asd_layer_t"""
     _fields_ = [("ln1_w", _vp), ("qkv_w", _vp), ("qkv_b", _vp), ("o_w", _vp), ("ln2_w", _vp), ("gate_up_w", _vp), ("down_w", _vp),
-                ("k_cache", _vp), ("vt_cache", _vp)]
+                ("k_cache", _vp), ("vt_cache", _vp), ("weights_packed", _i)]
 
 
 class DecoderShape(C.Structure):

@@ -557,16 +557,17 @@ ASD_EXPORT int asd_decoder_forward(const asd_layer_t* layers, int n_layers, cons
         const asd_layer_t& L = layers[l];
         if (!L.ln1_w || !L.qkv_w || !L.o_w || !L.ln2_w || !L.gate_up_w || !L.down_w || !L.k_cache || !L.vt_cache) return ASD_ERR_INVALID_ARG;
         int ks = 1;
+        const int64_t ldw_h = L.weights_packed ? 0 : s.hidden, ldw_i = L.weights_packed ? 0 : s.intermediate;   // 0: tile-major image
         if (!have_hn) rc = rmsnorm_run(x, ld_x, L.ln1_w, s.rms_eps, dt, M, s.hidden, hn, s.hidden, stream, Slabs{});
-        if (rc == ASD_OK) rc = asd_linear_partial(hn, s.hidden, L.qkv_w, s.hidden, L.qkv_b, nullptr, 0, dt, M, qkv_w, s.hidden, qkv, qkv_w, lin, lin_bytes, stream, &ks);
+        if (rc == ASD_OK) rc = asd_linear_partial(hn, s.hidden, L.qkv_w, ldw_h, L.qkv_b, nullptr, 0, dt, M, qkv_w, s.hidden, qkv, qkv_w, lin, lin_bytes, stream, &ks);
         if (rc == ASD_OK) rc = rope_kv_run(qkv, qkv_w, pos, rows, s.inv_freq, dt, B, T, s.heads, s.kv_heads, s.head_dim, L.k_cache, L.vt_cache, s.t_max, stream,
                                            slabs_of(lin, ks, M, qkv_w), L.qkv_b);
         if (rc == ASD_OK) rc = asd_attn_ragged(qkv, qkv_w, L.k_cache, L.vt_cache, pos, rows, dt, B, T, s.heads, s.kv_heads, s.head_dim, s.t_max, attn, s.hidden, stream);
-        if (rc == ASD_OK) rc = asd_linear_partial(attn, s.hidden, L.o_w, s.hidden, nullptr, x, ld_x, dt, M, s.hidden, s.hidden, x, ld_x, lin, lin_bytes, stream, &ks);
+        if (rc == ASD_OK) rc = asd_linear_partial(attn, s.hidden, L.o_w, ldw_h, nullptr, x, ld_x, dt, M, s.hidden, s.hidden, x, ld_x, lin, lin_bytes, stream, &ks);
         if (rc == ASD_OK) rc = rmsnorm_run(x, ld_x, L.ln2_w, s.rms_eps, dt, M, s.hidden, hn, s.hidden, stream, slabs_of(lin, ks, M, s.hidden));
-        if (rc == ASD_OK) rc = asd_linear_partial(hn, s.hidden, L.gate_up_w, s.hidden, nullptr, nullptr, 0, dt, M, 2 * s.intermediate, s.hidden, gu, gu_w, lin, lin_bytes, stream, &ks);
+        if (rc == ASD_OK) rc = asd_linear_partial(hn, s.hidden, L.gate_up_w, ldw_h, nullptr, nullptr, 0, dt, M, 2 * s.intermediate, s.hidden, gu, gu_w, lin, lin_bytes, stream, &ks);
         if (rc == ASD_OK) rc = silu_mul_run(gu, gu_w, dt, M, s.intermediate, act, s.intermediate, stream, slabs_of(lin, ks, M, 2 * s.intermediate));
-        if (rc == ASD_OK) rc = asd_linear_partial(act, s.intermediate, L.down_w, s.intermediate, nullptr, x, ld_x, dt, M, s.hidden, s.intermediate, x, ld_x, lin, lin_bytes, stream, &ks);
+        if (rc == ASD_OK) rc = asd_linear_partial(act, s.intermediate, L.down_w, ldw_i, nullptr, x, ld_x, dt, M, s.hidden, s.intermediate, x, ld_x, lin, lin_bytes, stream, &ks);
         if (rc != ASD_OK) break;
         // the norm that follows the down projection: the next layer's ln1, or the final norm
         const bool last = l + 1 == n_layers;

@@ -1491,7 +1491,8 @@ int linear_run(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const v
     if (residual && (ld_res < N || ld_res % 4 != 0 || !aligned_to(residual, 8))) return ld_res < N ? ASD_ERR_INVALID_ARG : ASD_ERR_ALIGNMENT;
     if (M == 0) return ASD_OK;
     if ((dtype != ASD_DTYPE_BF16 && dtype != ASD_DTYPE_F16) || D % kSuper != 0 || N % 4 != 0) return ASD_ERR_UNSUPPORTED;
-    if (!x || !w || !y || ld_x < D || ld_w < D || ld_y < N) return ASD_ERR_INVALID_ARG;
+    const bool packed = ld_w == 0;        // ld_w == 0: `w` is the tile-major image asd_lm_head_pack_weights writes (N rows, D columns)
+    if (!x || !w || !y || ld_x < D || (!packed && ld_w < D) || ld_y < N) return ASD_ERR_INVALID_ARG;
     if (!aligned_to(x, 16) || !aligned_to(w, 16) || !aligned_to(y, 8) || (bias && !aligned_to(bias, 8)) || ld_x % 8 != 0 ||
         ld_w % 8 != 0 || ld_y % 4 != 0)
         return ASD_ERR_ALIGNMENT;
@@ -1508,6 +1509,7 @@ int linear_run(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const v
     p.D = D; p.M = M; p.V = N;
     p.m_blocks = pl.kind == 3 ? 1 : (M + kBM - 1) / kBM;
     p.n_blocks = (N + 255) / 256;
+    p.packed = packed ? 1 : 0;
     p.k_slices = pl.k_slices;
     p.slabs = static_cast<float*>(workspace);
     p.out = y; p.ld_out = ld_y; p.bias = bias; p.residual = residual; p.ld_res = ld_res;

@@ -816,7 +816,8 @@ def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: Hie
                      max_new_tokens: int, predictor, ops=None, dtype: torch.dtype = torch.bfloat16,
                      heads: Sequence[str] = ("logits", "fused"), logit_scale: float = 1.0, seeds: Sequence[int] = (1, 2, 3),
                      keep_inputs: bool = False, weight_noise: Sequence[float] = (0.0, 0.0, 0.0), share_seed: Optional[int] = None,
-                     hip_layers: Optional[bool] = None) -> Tuple[Optional[DraftRole], Dict[int, VerifyRole]]:
+                     hip_layers: Optional[bool] = None, pack_weights: bool = False
+                     ) -> Tuple[Optional[DraftRole], Dict[int, VerifyRole]]:
     """The roles `rank` hosts under `placement`: tier 0 + verify tiers, models built on prompt_ids.device.
     shapes: one synthetic_lm.LMShape per tier.  heads[s-1]: "logits" (lm_head GEMM + asd_verify_accept), "fused"
     (asd_lm_head_verify from hidden states); a tier placed on several ranks gets a ShardedHead over those ranks
@@ -837,7 +838,10 @@ def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: Hie
                         logit_scale=logit_scale)
         can = dev.type == "cuda" and dtype == torch.bfloat16 and shapes[i].head_dim == 128
         if hip_layers or (hip_layers is None and can):
-            m.enable_hip_layers()
+            # pack_weights: the projection matrices re-laid tile-major in place (HipDecoder) where every row count allows it
+            packable = pack_weights and all(n % 256 == 0 for n in (shapes[i].hidden, shapes[i].hidden + 2 * shapes[i].kv_heads * shapes[i].head_dim,
+                                                                  2 * shapes[i].intermediate))
+            m.enable_hip_layers(pack_weights=packable)
         if weight_noise[i]:
             g = torch.Generator(device=dev).manual_seed(1000 + i)
             with torch.no_grad():

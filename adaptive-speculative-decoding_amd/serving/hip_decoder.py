@@ -19,7 +19,11 @@ from .. import kernels as K
 
 
 class HipDecoder:
-    def __init__(self, lm):
+    def __init__(self, lm, pack_weights: bool = False):
+        """pack_weights: re-lay every projection matrix tile-major IN ITS OWN STORAGE (asd_lm_head_pack_weights: a column block's
+        64-deep reduction step becomes one contiguous 32 KiB run instead of 256 strided lines; same results bit for bit, 3-7 %
+        less time per projection).  Needs every matrix's row count to be a multiple of 256 (all Qwen2.5 shapes); the torch
+        modules of this model then hold re-laid bytes and must not be used any more (SyntheticLM refuses)."""
         p = next(lm.parameters())
         if not p.is_cuda or p.dtype != torch.bfloat16:
             raise RuntimeError("HipDecoder needs a bf16 SyntheticLM on a CUDA device (there is no CPU path)")
@@ -43,6 +47,21 @@ class HipDecoder:
                 gu_w = torch.cat([blk.gate.weight.data, blk.up.weight.data], dim=0).contiguous()
                 blk.gate.weight.data, blk.up.weight.data = gu_w[:s.intermediate], gu_w[s.intermediate:]
                 self._fused.append((qkv_w, qkv_b, gu_w))
+        self.packed = False
+        if pack_weights:
+            mats = [m for i, blk in enumerate(lm.blocks) for m in (self._fused[i][0], blk.o.weight.data, self._fused[i][2], blk.down.weight.data)]
+            if all(m.shape[0] % 256 == 0 and m.shape[1] % 64 == 0 and m.is_contiguous() for m in mats):
+                tmp = torch.empty(max(m.numel() for m in mats), dtype=torch.bfloat16, device=dev)
+                for m in mats:
+                    N, D = m.shape
+                    assert int(self.lib.asd_lm_head_packed_bytes(N, D)) == m.numel() * 2
+                    rc = self.lib.asd_lm_head_pack_weights(m.data_ptr(), D, B.DTYPE_BF16, N, D, tmp.data_ptr(), m.numel() * 2, K._stream())
+                    B.check("asd_lm_head_pack_weights", rc)
+                    m.view(-1).copy_(tmp[: m.numel()])
+                del tmp
+                self.packed = True
+            else:
+                raise RuntimeError("HipDecoder(pack_weights=True): a projection's row count is not a multiple of 256")
         self.t_max = 0
         self.k_cache = []
         self.vt_cache = []
@@ -64,7 +83,7 @@ class HipDecoder:
             qkv_w, qkv_b, gu_w = self._fused[i]
             arr[i] = B.Layer(blk.ln1.weight.data_ptr(), qkv_w.data_ptr(), qkv_b.data_ptr(), blk.o.weight.data_ptr(),
                              blk.ln2.weight.data_ptr(), gu_w.data_ptr(), blk.down.weight.data_ptr(),
-                             self.k_cache[i].data_ptr(), self.vt_cache[i].data_ptr())
+                             self.k_cache[i].data_ptr(), self.vt_cache[i].data_ptr(), 1 if self.packed else 0)
         self._layers = arr
         self._shape = B.DecoderShape(s.hidden, s.heads, s.kv_heads, s.head_dim, s.intermediate, float(s.rms_eps),
                                      self.inv_freq.data_ptr(), self.t_max)

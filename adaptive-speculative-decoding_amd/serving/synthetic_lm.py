@@ -201,13 +201,16 @@ class SyntheticLM(nn.Module):
         self._graphs = {} if on else None
         self._max_graphs = int(max_graphs)
 
-    def enable_hip_layers(self, on: bool = True) -> None:
+    def enable_hip_layers(self, on: bool = True, pack_weights: bool = False) -> None:
         """Run forward_ragged through asd_decoder_forward (X3: csrc/decoder.hip + asd_linear; nine launches per layer, one host
         call per pass) instead of the torch modules.  CUDA + bf16 + head_dim 128 only; raises otherwise -- no fallback.  Call
         before alloc_ragged.  The lock-step `forward` / `truncate` cache keeps the torch modules."""
+        if getattr(self, "_weights_relaid", False) and not on:
+            raise RuntimeError("this model's projection matrices were re-laid tile-major for the HIP decoder stack: the torch modules cannot run it any more")
         if on:
             from .hip_decoder import HipDecoder
-            self._hip = HipDecoder(self)
+            self._hip = HipDecoder(self, pack_weights=pack_weights)
+            self._weights_relaid = self._hip.packed
         else:
             self._hip = None
         self._ragged = None
@@ -294,6 +297,8 @@ class SyntheticLM(nn.Module):
 
         return_hidden=True stops before the lm_head and returns the final-norm states [B, T, D]: the input
         of asd_lm_head_verify (logits = hidden @ lm_head.weight.T * logit_scale are then never materialised)."""
+        if getattr(self, "_weights_relaid", False):
+            raise RuntimeError("projection matrices re-laid for the HIP decoder stack: use forward_ragged")
         B, T = ids.shape
         pos = torch.arange(self._len, self._len + T, device=ids.device)
         x = self.embed(ids)

@@ -240,7 +240,8 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
     # for the torch modules of rounds 1-3 (~50 launches per layer) as the comparison
     hip_layers = False if os.environ.get("ASD_LOOP_TORCH_MODULES", "0") == "1" else None
     draft, tiers = H.build_rank_roles(rank, pl, shp, cfg, prompt, new_tokens, pred, ops=ops, heads=heads,
-                                      logit_scale=logit_scale, seeds=(1, 2, 3), hip_layers=hip_layers)
+                                      logit_scale=logit_scale, seeds=(1, 2, 3), hip_layers=hip_layers,
+                                      pack_weights=os.environ.get("ASD_LOOP_PACK_WEIGHTS", "1") == "1")
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     L = len(shp)

@@ -196,6 +196,8 @@ int asd_lm_head_partial(const void* hidden, int64_t ld_h, const void* weight_sha
  * reduction slices whose f32 partials meet in `workspace` and are added in slice order (bit-reproducible).
  * x, w, bias (may be NULL), y: all bf16 or all f16 (dtype); f32 accumulation, ONE rounding at the store.
  * D % 64 == 0, N % 4 == 0, x / w 16-byte aligned with ld % 8 == 0, y 8-byte aligned with ld_y % 4 == 0.
+ * ld_w == 0: w is the tile-major image asd_lm_head_pack_weights(w, ld, dtype, N, D, ...) writes (asd_lm_head_packed_bytes(N, D)
+ * bytes: N * D * 2 when N % 256 == 0, so a matrix can be re-laid in its own storage); same results, bit for bit.
  * workspace: asd_linear_workspace_bytes(M, N, D) bytes (no initialisation needed; may be shared by calls on one stream). */
 size_t asd_linear_workspace_bytes(int M, int N, int D);
 int asd_linear(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, int dtype, int M, int N, int D,
@@ -242,6 +244,7 @@ typedef struct asd_layer {
     const void* down_w;     /* [hidden][intermediate] */
     void* k_cache;
     void* vt_cache;
+    int weights_packed;     /* != 0: the four matrices are tile-major images (asd_lm_head_pack_weights of each, see asd_linear) */
 } asd_layer_t;
 typedef struct asd_decoder_shape {
     int hidden, heads, kv_heads, head_dim, intermediate;

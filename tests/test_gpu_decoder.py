@@ -365,3 +365,24 @@ def test_decoder_entry_points_reject_bad_arguments():
     assert lib.asd_decoder_forward(None, 1, C.byref(shp), x4.data_ptr(), 256, p4.data_ptr(), None, 4, 1, None, None, 0, base, need, None) < 0   # layers missing
     assert lib.asd_decoder_forward(None, 0, C.byref(shp), x4.data_ptr(), 256, p4.data_ptr(), None, 4, 1, w.data_ptr(), None, 0, base, need, None) < 0  # norm without out
     assert lib.asd_decoder_forward(None, 0, C.byref(shp), x4.data_ptr(), 256, p4.data_ptr(), None, 4, 1, None, None, 0, base, 16, None) < 0        # scratch too small
+
+
+def test_hip_decoder_with_weights_relaid_in_place_gives_the_same_bits():
+    SL = import_module("adaptive-speculative-decoding_amd.serving.synthetic_lm")
+    shape = SL.LMShape("small256", 512, 2, 4, 2, 1024, vocab=1000, rope_theta=1.0e6)      # 1024 | 512 | 2048 | 512 rows: all % 256
+    a = SL.SyntheticLM(shape, dtype=BF, device="cuda", seed=9)
+    b = SL.SyntheticLM(shape, dtype=BF, device="cuda", seed=9)
+    a.enable_hip_layers()
+    b.enable_hip_layers(pack_weights=True)
+    assert b._hip.packed and not a._hip.packed
+    oa = _run_sequence(a, 3, 20, 3, 5, seed=2)
+    ob = _run_sequence(b, 3, 20, 3, 5, seed=2)
+    for x, y in zip(oa, ob):
+        assert torch.equal(x, y)
+    with pytest.raises(RuntimeError):
+        b.forward(torch.zeros(1, 2, dtype=torch.int64, device="cuda"))            # the torch modules would read re-laid bytes
+    with pytest.raises(RuntimeError):
+        b.enable_hip_layers(False)
+    odd = SL.SyntheticLM(_small_shape(), dtype=BF, device="cuda", seed=9)
+    odd_shape_ok = all(n % 256 == 0 for n in (512, 512 + 2 * 2 * 128, 2 * 1024))
+    assert odd_shape_ok                                                                  # (_small_shape packs too)

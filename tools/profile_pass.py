@@ -24,10 +24,11 @@ def main():
     ap.add_argument("--graphs", action="store_true")
     ap.add_argument("--hip-layers", action="store_true")
     ap.add_argument("--hidden-only", action="store_true")
+    ap.add_argument("--pack", action="store_true", help="projection matrices re-laid tile-major in place")
     a = ap.parse_args()
     lm = SL.SyntheticLM(SL.QWEN25_SHAPES[a.model], device="cuda", seed=1, logit_scale=0.6)
     if a.hip_layers:
-        lm.enable_hip_layers()
+        lm.enable_hip_layers(pack_weights=a.pack)
     lm.alloc_ragged(a.batch, a.cap)
     g = torch.Generator(device="cuda").manual_seed(3)
     ids = torch.randint(0, lm.shape.vocab, (a.batch, a.prompt), generator=g, device="cuda")
