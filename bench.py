@@ -37,6 +37,11 @@ Event PAIRS around single launches are not used: on this stack a pair adds 5-15 
 a ~16 us kernel (measured in round 1: 19.8 us per pair vs 16.6 us rocprofv3), and recording them
 inside the timed region would slow the very loop `value` is computed from.  cpu_baseline: the C oracle (oracle/,
 OpenMP over rows) on the host cores, same workload, bounded sample, rank 0 at N = 1 only.
+
+`loop` (N = 1, after the headline measurement): the token-level three-tier loop of BASELINE configs[2] / [3] on synthetic
+7B / 32B / 72B-shape models.  Their passes run on the HIP decoder stack (asd_decoder_forward: asd_linear + csrc/decoder.hip,
+DESIGN 4.9) with the projection matrices re-laid tile-major in place; ASD_LOOP_TORCH_MODULES=1 runs the torch modules of rounds
+1-3a instead, ASD_LOOP_PACK_WEIGHTS=0 keeps the [N][D] layout.  `loop.model_execution` says which code ran per tier.
 """
 from __future__ import annotations
 
