@@ -317,3 +317,15 @@ def test_a_rank_without_a_role_returns_at_once():
     assert sorted({pl.draft} | {r for t in pl.tiers for r in t}) == [0, 1, 2, 3, 4, 5]
     tr = H.run_hierarchical_rank(7, pl, None, {}, B, K, 3, V, torch.float32, P + NEW, torch.device("cpu"), max_steps=2)
     assert tr.steps == 0 and tr.verified_tokens == 0
+
+
+def test_required_hip_layers_fail_loudly_on_cpu():
+    """build_rank_roles(hip_layers=True) demands the HIP decoder stack: on a CPU device that is an error, never a silent
+    return to the torch modules (hip_layers=None picks the torch modules there and says so in `model.execution`)."""
+    from asd_amd.serving import hierarchy as H
+    from asd_amd.serving.synthetic_lm import tiny
+    from tests.oracle_backend import OracleOps
+    cfg = _cfg()
+    prompt = _prompt()
+    with pytest.raises(RuntimeError):
+        H.build_rank_roles(0, H.Placement.for_world(1), [tiny(vocab=V)] * 3, cfg, prompt, 8, _predictor(), ops=OracleOps(), hip_layers=True)
