@@ -22,6 +22,7 @@ MAX_STAGES = 16
 MAX_SPLITS = 64
 MAX_MLP_DIM = 1024
 NUM_LP_STATS = 5
+WS_LOST_HANDOFF = 0x1
 
 _vp, _i, _i64, _d, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t, C.c_float
 
@@ -32,6 +33,7 @@ SIGNATURES = {
     "asd_device_cu_count": (_i, [_i]),
     "asd_verify_accept_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "asd_workspace_init": (_i, [_vp, _sz, _vp]),
+    "asd_workspace_status": (_i, [_vp, _vp, _vp]),
     "asd_verify_accept": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "asd_verify_accept_ex": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "asd_verify_accept_stats": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _f, _vp]),

@@ -8,6 +8,10 @@
 
 #include <math.h>
 
+#ifndef ASD_EPI_STAMP
+#define ASD_EPI_STAMP(slot) do { } while (0)   // stage stamps: the diagnostic build of verify_accept.hip only (tools/stamp_verify.py)
+#endif
+
 namespace asd {
 
 // ---- numpy pairwise summation (numpy/_core/src/umath/loops_utils.h.src: pairwise_sum) -----
@@ -174,6 +178,114 @@ __device__ __forceinline__ void wave_logprob_stats_lanes(double v, int n, int la
     out[4] = (n & 1) ? sorted_at(n / 2) : (sorted_at(n / 2 - 1) + sorted_at(n / 2)) / 2.0;
 }
 
+// ---- the five statistics once more, for n <= 16 values held one per lane of the wave's first row (the serving shapes:
+// K = 4 ... 16).  A single wave runs the in-kernel epilogue behind the last row of its sequence, so what it costs is its
+// INSTRUCTION COUNT (one VALU instruction per ~4-8 cycles, nothing to overlap with): the readlane form above spends
+// ~1.3 us of a 2.2 us epilogue on ~700 instructions (profiles/r04_stamps_c3_fused_stages.log).  Here:
+//  * numpy's pairwise leaf sum as a DPP tree -- quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror give lane 0
+//    ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), operand for operand numpy's expression (a + b = b + a bit for bit, so the other
+//    lanes' mirrored operands do not matter); n = 16 first folds a[8+j] onto r[j] (row_shl:8); the n % 8 tail stays a
+//    sequential chain of v_readlane adds;
+//  * sum / n as a multiplication by 2^-k when n is a power of two (both are the correctly rounded value of the same real
+//    number: identical bits, one instruction instead of the ~25 of an f64 division);
+//  * the order statistics from a bitonic sorting network (with flips) over order-preserving integer keys of the f32
+//    log-probs -- v_min_u32 / v_max_u32 with a DPP operand + one v_cndmask per stage, 6 stages for n <= 8, 10 for n <= 16 --
+//    instead of the O(n) readlane rank loop.  The sorted VALUES are those of the stable rank sort (only the order among
+//    +0 / -0, which numpy does not define either, can differ).
+// Same arithmetic as wave_logprob_stats / wave_logprob_stats_lanes for the sums, the std, the percentile and the median.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(b)), CTRL, 0xf, 0xf, true));
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(b >> 32)), CTRL, 0xf, 0xf, true));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+// numpy's pairwise_sum leaf over n <= 16 doubles, lane i < n of row 0 holding a[i]; the result is wave-uniform
+__device__ __forceinline__ double np_sum_leaf_row16(double v, int n) {
+    double res = 0.0;
+    int i = 0;
+    if (n >= 8) {
+        double r = v;                                    // r[j] = a[j]
+        if (n == 16) r = r + dpp_f64<0x108>(v);          // row_shl:8   r[j] += a[8 + j]
+        r = r + dpp_f64<0xB1>(r);                        // quad_perm [1,0,3,2]   (r0+r1) (r2+r3) (r4+r5) (r6+r7)
+        r = r + dpp_f64<0x4E>(r);                        // quad_perm [2,3,0,1]   (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)
+        r = r + dpp_f64<0x141>(r);                       // row_half_mirror       ((..)+(..)) + ((..)+(..))
+        res = bcast_lane0(r);
+        i = n - (n & 7);
+    }
+    for (; i < n; ++i) res = res + lane_value(v, i);     // n < 8: numpy's sequential loop from 0.0; otherwise the n % 8 tail
+    return res;
+}
+// f32 <-> unsigned key with the same order (-inf < ... < -0 < +0 < ... < +inf < NaN)
+__device__ __forceinline__ uint32_t f32_order_key(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return b ^ (static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(uint32_t k) {
+    return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t sort_step(uint32_t k, bool low) {       // compare-exchange with the lane CTRL names
+    const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(k), static_cast<int>(k), CTRL, 0xf, 0xf, false));
+    const uint32_t lo = k < o ? k : o, hi = k < o ? o : k;
+    return low ? lo : hi;
+}
+// lpv: this lane's log-prob (lanes < n of row 0), n <= 16; out: the five numbers, the same in every lane
+__device__ __forceinline__ void wave_logprob_stats_row16(float lpv, int n, int lane, double (&out)[5]) {
+    if (n <= 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) out[i] = 0.0;
+        return;
+    }
+    const bool pow2 = (n & (n - 1)) == 0;
+    const double dn = static_cast<double>(n);
+    const double inv_n = __builtin_bit_cast(double, static_cast<unsigned long long>(1023 - __builtin_ctz(static_cast<unsigned>(n))) << 52);
+    const double v = static_cast<double>(lpv);
+    const double sum = np_sum_leaf_row16(v, n);
+    double mean, var;
+    if (pow2) mean = sum * inv_n; else mean = sum / dn;                       // np.mean
+    const double t = v - mean;
+    const double ssq = np_sum_leaf_row16(t * t, n);
+    if (pow2) var = ssq * inv_n; else var = ssq / dn;                         // np.std (population)
+    // sort (ascending, lanes 0..15 of the row; lanes >= n hold the largest key)
+    uint32_t k = lane < n ? f32_order_key(lpv) : 0xFFFFFFFFu;
+    const bool b0 = (lane & 1) == 0, b1 = (lane & 2) == 0, b2 = (lane & 4) == 0, b3 = (lane & 8) == 0;
+    k = sort_step<0xB1>(k, b0);                                               // blocks of 2
+    k = sort_step<0x1B>(k, b1);                                               // blocks of 4: mirror [3,2,1,0], then stride 1
+    k = sort_step<0xB1>(k, b0);
+    k = sort_step<0x141>(k, b2);                                              // blocks of 8: row_half_mirror, strides 2, 1
+    k = sort_step<0x4E>(k, b1);
+    k = sort_step<0xB1>(k, b0);
+    if (n > 8) {
+        k = sort_step<0x140>(k, b3);                                          // blocks of 16: row_mirror, strides 4, 2, 1
+        {   // stride 4 has no single DPP pattern: row_ror:4 (lane i <- i - 4) serves the lanes with bit 2 set (banks 1, 3),
+            // row_ror:12 (lane i <- i + 4) the others (banks 0, 2)
+            uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(k), static_cast<int>(k), 0x124, 0xf, 0xA, false));
+            o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(o), static_cast<int>(k), 0x12C, 0xf, 0x5, false));
+            const uint32_t lo = k < o ? k : o, hi = k < o ? o : k;
+            k = b2 ? lo : hi;
+        }
+        k = sort_step<0x4E>(k, b1);
+        k = sort_step<0xB1>(k, b0);
+    }
+    auto sorted_at = [&](int r) -> double {                                   // r wave-uniform, 0 <= r < n
+        return static_cast<double>(f32_from_order_key(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(k), r))));
+    };
+    const int lo = (n - 1) >> 2;                                              // floor((n - 1) * 0.25)
+    const int hi = lo + 1 < n ? lo + 1 : n - 1;
+    const double frac = static_cast<double>((n - 1) & 3) * 0.25;              // (n - 1) * 0.25 - lo, exactly
+    out[0] = mean;
+    out[1] = sqrt(var);
+    out[2] = sorted_at(0);
+    out[3] = np_lerp(sorted_at(lo), sorted_at(hi), frac);
+    out[4] = (n & 1) ? sorted_at(n / 2) : (sorted_at(n / 2 - 1) + sorted_at(n / 2)) / 2.0;
+}
+// n <= 64 values one per lane: the DPP form where it applies, the readlane form otherwise (wave-uniform choice)
+__device__ __forceinline__ void wave_logprob_stats_regs(float lpv, int n, int lane, double (&out)[5]) {
+    if (n <= 16) wave_logprob_stats_row16(lpv, n, lane, out);
+    else wave_logprob_stats_lanes(static_cast<double>(lpv), n, lane, out);
+}
+
 // ---- fused epilogue: parameters and the lane-0 decision tail -----------------------------
 struct FusedParams {
     const float* lp; int64_t ld_lp; const int32_t* n_valid; int K;
@@ -260,7 +372,15 @@ __device__ __forceinline__ void decide_and_store_small(const FusedParams& p, int
                 pp[i] = (i == p.stage_idx) ? prob : d.ph[i];
                 cc[i] = d.cc[i];
             }
-            const int ks = optimal_stopping_n<kDecidePrefetch>(pp, cc, p.lam, n_dp, 0, 1.0, 1.0, J);
+            int ks;
+            static_assert(kDecidePrefetch == 4, "the depth switch below lists 1 ... 4");
+            (void)J;
+            switch (n_dp) {                                              // wave-uniform
+                case 1: ks = optimal_stopping_exact<1>(pp, cc, p.lam); break;
+                case 2: ks = optimal_stopping_exact<2>(pp, cc, p.lam); break;
+                case 3: ks = optimal_stopping_exact<3>(pp, cc, p.lam); break;
+                default: ks = optimal_stopping_exact<4>(pp, cc, p.lam); break;
+            }
             if (p.k_star) p.k_star[b] = ks;
             if (p.stop) p.stop[b] = (ks == p.stage_idx) ? 1 : 0;
         }
@@ -276,10 +396,19 @@ __device__ __forceinline__ void decide_and_store(const FusedParams& p, int b, fl
 }
 
 // ---- the reference's predictor (64 -> 32 -> 1), one wave per sequence ---------------------
-// Everything that does not depend on the log-probs, fetched up front: the first layer is split over
-// the two half-waves (lane = hidden unit j, half = input half), its weights live in registers.
+// CANONICAL ORDER of the latency forms (k_predictor_stop_w64x32 and the in-kernel epilogue of k_verify<FUSED>; round 4).
+// The first layer is split over the two half-waves (lane = hidden unit j, half = input half).  Only the five statistics
+// columns [stats_col, stats_col + 5) of the feature vector depend on the log-probs, so they are accumulated LAST:
+//   phase A   h = 0;  for i = 0..31:  h = fma(W1[j][32 half + i], x'[32 half + i], h)      x' = the feature row with the
+//                                                                                           statistics columns zeroed
+//   phase B   for d = 0..4:  c = stats_col + d;  h = fma(W1[j][c], (half == c / 32) ? stat[d] : 0, h)
+//   then      h = h(half 0) + h(half 1);  h = relu(h + b1[j]);  z = wave_sum(half == 0 ? W2[j] h : 0);  sigmoid(z + b2)
+// Phase A needs nothing the verify pass produces: the in-kernel epilogue runs it UNDER the wait for the hand-off slots,
+// and what is left behind the statistics is five FMAs instead of a 32-step chain.  Both latency forms use this order, so
+// their scores stay bit-identical (tests/test_gpu_predictor.py); against the oracle the bar is 1e-5 as before.
 struct EpiPrefetch {
     float w[32];
+    float wd[ASD_NUM_LP_STATS];   // W1[j][stats_col + d]: the deferred columns' weights for this lane's hidden unit
     float b1, w2, b2, xv;
     DecidePrefetch d;      // lane 0 only
 };
@@ -289,28 +418,52 @@ __device__ __forceinline__ void epi_prefetch(const FusedParams& p, int b, int la
     const int j = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 32; ++i) e.w[i] = p.packed[(half * 32 + i) * 32 + j];
+#pragma unroll
+    for (int d = 0; d < ASD_NUM_LP_STATS; ++d) e.wd[d] = p.stats_col >= 0 ? p.packed[(p.stats_col + d) * 32 + j] : 0.0f;
     e.b1 = p.packed[64 * 32 + j];
     e.w2 = p.packed[64 * 32 + 32 + j];
     e.b2 = p.packed[64 * 32 + 64];
     if (lane == 0) decide_prefetch(p, b, e.d);
 }
 
-// lpv: this lane's log-prob (lanes < n).  dvals: 3*64 doubles of LDS, xs: 64 floats of LDS (16-byte aligned).
+// the feature row with the statistics columns zeroed (phase A's input), one value per lane
+__device__ __forceinline__ float epi_phase_a_input(const FusedParams& p, int lane, float xv) {
+    const int si = lane - p.stats_col;
+    return (p.stats_col >= 0 && si >= 0 && si < ASD_NUM_LP_STATS) ? 0.0f : xv;
+}
+// both halves' sums in every lane: v_permlane32_swap (gfx950) exchanges the upper half of one copy with the lower half of the
+// other -- one VALU instruction where __shfl_xor(h, 32) is a ds_bpermute round trip
+__device__ __forceinline__ float add_halves(float h) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(h), __float_as_uint(h), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);      // (half 0's h) + (half 1's h) in every lane
+}
+// phase B and everything behind it; h: phase A's accumulator, wd: the deferred columns' weights, st: the statistics (uniform)
+template <typename WD>
+__device__ __forceinline__ float epi_score(const FusedParams& p, int lane, float h, const WD& wd, const double (&st)[5], bool overlay,
+                                           float b1, float w2, float b2) {
+    const int half = lane >> 5;
+    if (overlay) {
+#pragma unroll
+        for (int d = 0; d < ASD_NUM_LP_STATS; ++d) {
+            const float sd = (half == ((p.stats_col + d) >> 5)) ? static_cast<float>(st[d]) : 0.0f;
+            h = fmaf(wd(d), sd, h);
+        }
+    }
+    h = add_halves(h);
+    h = fmaxf(h + b1, 0.0f);
+    const float z = wave_sum(half == 0 ? w2 * h : 0.0f);     // one DPP wave sum, fixed order
+    ASD_EPI_STAMP(10);   // both layers done
+    // sigmoid on the hardware's 2^x and 1/x (v_exp_f32, v_rcp_f32: 1 ulp each; the score moves by < 2e-7, the bar against the
+    // reference is 1e-5): 5 instructions where expf + an IEEE division are ~33 -- and a single wave's instruction count is what
+    // this epilogue costs.  Both latency forms share this function, so their scores stay bit-identical.
+    const float e = __builtin_amdgcn_exp2f(-(z + b2) * kLog2e);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// lpv: this lane's log-prob (lanes < n).  xs: 64 floats of LDS (16-byte aligned).
 __device__ __forceinline__ void epi_finish(const FusedParams& p, int b, int lane, float lpv, int n, bool want_stats,
                                            const EpiPrefetch& e, double* dvals, float* xs) {
-    float xv = e.xv;
-    if (want_stats) {
-        double st[5];
-        wave_logprob_stats_lanes(static_cast<double>(lpv), n, lane, st);      // n <= 64 values, one per lane: registers + readlane only
-        if (p.stats && lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
-        }
-        const int si = lane - p.stats_col;
-        if (p.stats_col >= 0 && si >= 0 && si < 5)
-            xv = static_cast<float>(si == 0 ? st[0] : si == 1 ? st[1] : si == 2 ? st[2] : si == 3 ? st[3] : st[4]);
-    }
-    xs[lane] = xv;
+    xs[lane] = epi_phase_a_input(p, lane, e.xv);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -318,55 +471,68 @@ __device__ __forceinline__ void epi_finish(const FusedParams& p, int b, int lane
     float h = 0.0f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) h = fmaf(e.w[i], xs[half * 32 + i], h);
-    h += __shfl_xor(h, 32, 64);
-    h = fmaxf(h + e.b1, 0.0f);
-    // the output unit: one DPP wave sum (fixed order; the ds_bpermute butterfly it replaces was five dependent LDS round trips)
-    const float z = wave_sum(half == 0 ? e.w2 * h : 0.0f);
-    const float sc = 1.0f / (1.0f + expf(-(z + e.b2)));
+    double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (want_stats) {
+        wave_logprob_stats_regs(lpv, n, lane, st);           // n <= 64 values, one per lane: registers, DPP / readlane only
+        if (p.stats && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
+        }
+    }
+    const float sc = epi_score(p, lane, h, [&](int d) { return e.wd[d]; }, st, want_stats && p.stats_col >= 0, e.b1, e.w2, e.b2);
     if (lane == 0) decide_and_store_impl<true>(p, b, sc, e.d);
 }
 
 
 // ---- the same epilogue for a kernel that cannot afford the weights in registers while it streams (k_verify<FUSED>:
 // 55 more VGPRs took it to 135 and to ONE workgroup per CU).  The packed weights sit in LDS (put there by LDS-DMA at the
-// kernel's start: no register is held across the stream); the feature and the decision inputs are loaded LATE -- issued by
-// the finisher right before it waits for the hand-off slots, i.e. under a wait that is there anyway.  Same operations in
-// the same order as epi_finish: bit-identical scores.
+// kernel's start: no register is held across the stream); the decision inputs are loaded LATE -- issued by the finisher right
+// before it waits for the hand-off slots, i.e. under a wait that is there anyway -- and phase A of the first layer runs under
+// that wait too (epi_phase_a_lds).  Same operations in the same order as epi_finish: bit-identical scores.
 struct EpiLate {
     float xv;
     DecidePrefetch d;      // lane 0 only
 };
 __device__ __forceinline__ void epi_late_prefetch(const FusedParams& p, int b, int lane, EpiLate& e) {
-    e.xv = p.feat[static_cast<int64_t>(b) * p.ldf + lane];
     if (lane == 0) decide_prefetch(p, b, e.d);
 }
-// wl: the 64 * 32 + 65 packed floats in LDS (W1^T [in][hidden], b1, W2, b2)
-__device__ __forceinline__ void epi_finish_lds(const FusedParams& p, int b, int lane, float lpv, int n, bool want_stats,
-                                               const float* wl, const EpiLate& e, double* dvals, float* xs) {
-    float xv = e.xv;
-    if (want_stats) {
-        double st[5];
-        wave_logprob_stats_lanes(static_cast<double>(lpv), n, lane, st);      // registers + readlane only (dvals unused)
-        if (p.stats && lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
-        }
-        const int si = lane - p.stats_col;
-        if (p.stats_col >= 0 && si >= 0 && si < 5)
-            xv = static_cast<float>(si == 0 ? st[0] : si == 1 ? st[1] : si == 2 ? st[2] : si == 3 ? st[3] : st[4]);
-    }
-    xs[lane] = xv;
+// what phase A leaves in registers for the rest: its accumulator and every weight the steps behind the statistics read (the
+// deferred columns', b1, W2, b2), fetched from LDS NOW so that no LDS round trip stands behind the hand-off
+struct EpiPhaseA {
+    float h, wd[ASD_NUM_LP_STATS], b1, w2, b2;
+};
+// wl: the 64 * 32 + 65 packed floats in LDS (W1^T [in][hidden], b1, W2, b2); xs: 64 floats of LDS scratch
+__device__ __forceinline__ void epi_phase_a_lds(const FusedParams& p, int lane, float xv, const float* wl, float* xs, EpiPhaseA& a) {
+    xs[lane] = epi_phase_a_input(p, lane, xv);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int j = lane & 31, half = lane >> 5;
+    const int col = p.stats_col >= 0 ? p.stats_col : 0;
+#pragma unroll
+    for (int d = 0; d < ASD_NUM_LP_STATS; ++d) a.wd[d] = wl[(col + d) * 32 + j];
+    a.b1 = wl[64 * 32 + j];
+    a.w2 = wl[64 * 32 + 32 + j];
+    a.b2 = wl[64 * 32 + 64];
     float h = 0.0f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) h = fmaf(wl[(half * 32 + i) * 32 + j], xs[half * 32 + i], h);
-    h += __shfl_xor(h, 32, 64);
-    h = fmaxf(h + wl[64 * 32 + j], 0.0f);
-    const float z = wave_sum(half == 0 ? wl[64 * 32 + 32 + j] * h : 0.0f);      // (same DPP order as epi_finish: bit-identical scores)
-    const float sc = 1.0f / (1.0f + expf(-(z + wl[64 * 32 + 64])));
+    a.h = h;
+}
+// a: epi_phase_a_lds's result
+__device__ __forceinline__ void epi_finish_lds(const FusedParams& p, int b, int lane, float lpv, int n, bool want_stats,
+                                               const EpiLate& e, const EpiPhaseA& a) {
+    double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (want_stats) {
+        wave_logprob_stats_regs(lpv, n, lane, st);
+        if (p.stats && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
+        }
+    }
+    ASD_EPI_STAMP(9);    // statistics done
+    const float sc = epi_score(p, lane, a.h, [&](int d) { return a.wd[d]; }, st, want_stats && p.stats_col >= 0, a.b1, a.w2, a.b2);
+    ASD_EPI_STAMP(11);   // sigmoid done
     if (lane == 0) decide_and_store_small(p, b, sc, e.d);
 }
 

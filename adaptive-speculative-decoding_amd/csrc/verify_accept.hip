@@ -52,8 +52,7 @@
 // (softmax -> index -> log -> .item(), one token per iteration).  The acceptance test has no
 // reference symbol; it is specified in include/asd_hip.h and DESIGN.md.
 
-#include "lse_device.hpp"
-#include "predictor_device.hpp"   // this TU is built with -ffp-contract=off (numpy / CPython parity of the epilogue)
+#include <hip/hip_runtime.h>
 
 #ifdef ASD_STAMP
 // Diagnostic build only (tools/stamp_verify.py builds a separate .so with -DASD_STAMP): per-workgroup
@@ -64,9 +63,13 @@ __device__ unsigned long long* g_asd_stamps = nullptr;
         if (threadIdx.x == 0 && g_asd_stamps)                                                    \
             g_asd_stamps[static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+#define ASD_EPI_STAMP(slot) ASD_STAMP_AT(slot)   // stage stamps inside the in-kernel epilogue (predictor_device.hpp)
 #else
 #define ASD_STAMP_AT(slot) do { } while (0)
 #endif
+
+#include "lse_device.hpp"
+#include "predictor_device.hpp"   // this TU is built with -ffp-contract=off (numpy / CPython parity of the epilogue)
 
 namespace asd {
 namespace {
@@ -113,6 +116,47 @@ __device__ __forceinline__ uint64_t poll_slot(uint64_t* slot) {
     return v;
 }
 
+// the rest of a poll whose first probe `v` was issued earlier (work was placed under it)
+__device__ __forceinline__ uint64_t poll_more(uint64_t* slot, uint64_t v) {
+#if defined(ASD_LAB) && ASD_LAB == 3      // lab: four probes in flight, ~0.15 us apart, each checked as it returns
+    for (int spins = 0; v == 0ull && spins < kSpinLimit; spins += 4) {
+        const uint64_t a = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_sleep(4);
+        const uint64_t b = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_sleep(4);
+        const uint64_t c = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_sleep(4);
+        const uint64_t d = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a != 0ull) { v = a; break; }
+        if (b != 0ull) { v = b; break; }
+        if (c != 0ull) { v = c; break; }
+        v = d;
+    }
+    return v;
+#elif defined(ASD_LAB) && ASD_LAB == 4    // lab: the siblings share this XCD -- read-and-clear in its L2 (workgroup-scope RMW)
+    for (int spins = 0; v == 0ull && spins < kSpinLimit; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_exchange(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return v;
+#else
+    for (int spins = 0; v == 0ull && spins < kSpinLimit; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return v;
+#endif
+}
+
+// A hand-off word that never arrived poisons its row / sequence AND is reported: the workspace's first word (the unused u32 at
+// +0 of sequence 0's ballot line) is a STICKY status, or-ed by whoever gave up, read by the host with asd_workspace_status
+// (or straight from the buffer) at a synchronisation it performs anyway, cleared only by asd_workspace_init.  A workspace
+// whose status is non-zero must be re-initialised before it is used again: the word that arrived late was never handed back
+// empty, so the "all-zero between calls" invariant no longer holds for it.
+__device__ __forceinline__ void report_lost(uint32_t* workspace_words) {
+    __hip_atomic_fetch_or(workspace_words, static_cast<uint32_t>(ASD_WS_LOST_HANDOFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // the epilogue's outputs for a sequence whose hand-off was lost: nothing downstream may read them as a verdict
 __device__ __forceinline__ void epi_poison(const FusedParams& e, int b) {
     if (e.score) e.score[b] = NAN;
@@ -122,6 +166,19 @@ __device__ __forceinline__ void epi_poison(const FusedParams& e, int b) {
     if (e.stats) {
         for (int i = 0; i < ASD_NUM_LP_STATS; ++i) e.stats[ASD_NUM_LP_STATS * static_cast<int64_t>(b) + i] = NAN;
     }
+}
+
+// k_verify's kernarg segment: (void*, int32_t*, int64_t, int, int, int, float, int) = 44 bytes, then the by-value VerifyParams
+// at the next multiple of its alignment
+constexpr int kKernargParamsOffset = 48;
+static_assert(alignof(VerifyParams) == 8, "kKernargParamsOffset assumes an 8-byte aligned parameter struct");
+// an opaque definition of a wave-uniform value: whatever is derived from it below cannot be re-loaded from the kernarg segment
+#define ASD_PIN(x) asm volatile("" : "+s"(x))
+__device__ __forceinline__ void pin_epilogue_params(FusedParams& e) {
+    ASD_PIN(e.K); ASD_PIN(e.feat); ASD_PIN(e.ldf); ASD_PIN(e.stats_col); ASD_PIN(e.packed);
+    ASD_PIN(e.risk); ASD_PIN(e.n_obs); ASD_PIN(e.alpha); ASD_PIN(e.beta);
+    ASD_PIN(e.p_hist); ASD_PIN(e.C); ASD_PIN(e.lam); ASD_PIN(e.L); ASD_PIN(e.stage_idx); ASD_PIN(e.prefix);
+    ASD_PIN(e.theta); ASD_PIN(e.score); ASD_PIN(e.k_star); ASD_PIN(e.stop); ASD_PIN(e.thr_stop); ASD_PIN(e.stats);
 }
 
 template <int DT, int UNROLL, bool CHECK, bool STATS>
@@ -184,7 +241,11 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     const float c2 = a_scale2;
     // grid = (rows, splits): no division stands between the wave's start and its first loads (as a 1-D grid the prologue
     // held three 64-bit and one 32-bit software divisions -- ~570 scalar instructions, ~2.8 us in the stamped build)
+#if defined(ASD_LAB) && ASD_LAB == 4      // lab: workgroup i runs on XCD i % 8 -- give every XCD a contiguous run of rows (whole sequences)
+    const int row = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+#else
     const int row = static_cast<int>(blockIdx.x);
+#endif
     const int split = static_cast<int>(blockIdx.y);
 
     const char* rowp = static_cast<const char*>(a_logits) + static_cast<int64_t>(row) * a_ld_row * E::kBytes;
@@ -256,32 +317,18 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         raw_lpd = reinterpret_cast<const uint32_t*>(p.lp_d)[vrow];
         raw_u = reinterpret_cast<const uint32_t*>(p.u)[vrow];
     }
-    uint32_t raw_head = 0, raw_tail = 0;
+    uint32_t raw_head = 0, raw_tail = 0, raw_feat = 0;
     const bool do_head = wave == 0 && split == 0 && lane < head;
     const bool do_tail = wave == 0 && split == S - 1 && lane >= 32 && lane - 32 < tail;
     if (do_head) raw_head = E::raw(rowp, lane);
     if (do_tail) raw_tail = E::raw(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + (lane - 32));
     const int b = static_cast<int>(static_cast<uint32_t>(row) / static_cast<uint32_t>(a_K));
     const int k = row - b * a_K;
+#if defined(ASD_LAB) && ASD_LAB == 7   // lab: the FUSED instantiation run as the plain kernel (its static cost alone)
+    const bool fused = FUSED && p.mode == 7;
+#else
     const bool fused = FUSED && p.mode == 0;   // one workgroup per row: the sequence's designated finisher; split rows: the last arriver
-    if (FUSED) {
-        // The predictor's 2113 packed weights go STRAIGHT into LDS (global_load_lds: no VGPR is held across the stream; as
-        // registers they took this instantiation to 135 VGPRs = one workgroup per CU), issued under the stream by the waves
-        // that can end up running the epilogue: the designated finisher (the sequence's last row) with one workgroup per row,
-        // any slice's wave 0 with split rows.  8 x 1 KiB (W1^T), then b1 / W2 (64 floats) and b2 as dwords.
-        if (fused && wave == 0 && (!own_row || k == a_K - 1)) {
-            typedef __attribute__((address_space(3))) void lds_void;
-            typedef const __attribute__((address_space(1))) void glb_void;
-            const char* src = reinterpret_cast<const char*>(p.epi.packed);
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps)
-                __builtin_amdgcn_global_load_lds((glb_void*)(src + ps * 1024 + lane * 16), (lds_void*)(reinterpret_cast<char*>(wlds) + ps * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(src + 8192 + lane * 4), (lds_void*)(reinterpret_cast<char*>(wlds) + 8192), 4, 0, 0);
-            if (lane == 0)
-                __builtin_amdgcn_global_load_lds((glb_void*)(src + 8192 + 256), (lds_void*)(reinterpret_cast<char*>(wlds) + 8192 + 256), 4, 0, 0);
-        }
-    }
-
+#endif
 #define ASD_CLAIM(dst)                                                                                   \
     do {                                                                                                 \
         uint32_t c_ = 0;                                                                                 \
@@ -325,12 +372,57 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     if (lane == 0 && g_asd_stamps)   // per-wave stream end, after the per-workgroup records
         g_asd_stamps[static_cast<size_t>(gridDim.x * gridDim.y) * 16 + static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (wave == 0) {
+    FusedParams ep;   // FUSED: the epilogue's parameters (wave 0 only; fetched below)
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) {   // (wave-uniform for the compiler too: the parameters below live in SGPRs)
         // the small loads issued ahead of the loop are consumed here: head / tail elements -> slot n_tiles,
         // the drafted token's logit and log(u) for lane 0
         // pin the first use of the loaded values HERE: without it the compiler hoists the (cheap, speculatable)
         // conversions up to the loads and waits for them in front of the loop
         asm volatile("" : "+v"(raw_x), "+v"(raw_head), "+v"(raw_tail), "+v"(raw_lpd), "+v"(raw_u));
+        if (FUSED) {
+            // The epilogue's parameters are fetched HERE -- behind the stream, by wave 0 alone, in one batch of scalar loads that
+            // completes under the barrier below -- through a kernarg pointer the compiler cannot see through, and pinned in SGPRs.
+            // Left to the compiler, the loads of the by-value struct land wherever their first use is: in round 3 right behind
+            // the FIRST barrier (the weight DMA used three of the fields there).  The kernarg segment is not served from a cache: a
+            // scalar load issued once the chip-wide burst of tile loads exists waits ~1 us behind 12 MB of streaming requests,
+            // and EVERY wave of EVERY workgroup waited for it before its first tile claim (profiles/r04_lab_bisect.json: fused
+            // without hand-off and epilogue 16.33 us, the same with that block compiled out 15.07 us, plain 15.37 us); the
+            // finisher's tail paid three more dependent waits of the same kind.
+            typedef const __attribute__((address_space(4))) char* ka_ptr;
+            typedef const __attribute__((address_space(4))) FusedParams* ka_epi_ptr;
+            ka_ptr ka = (ka_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            const ka_epi_ptr kp = (ka_epi_ptr)(ka + kKernargParamsOffset + __builtin_offsetof(VerifyParams, epi));
+            ep.lp = nullptr; ep.ld_lp = 0; ep.n_valid = nullptr; ep.in_dim = 64; ep.hidden = 32; ep.use_lds = 0; ep.B = 0;   // (unused by the in-kernel epilogue)
+            ep.K = kp->K; ep.feat = kp->feat; ep.ldf = kp->ldf; ep.stats_col = kp->stats_col; ep.packed = kp->packed;
+            ep.risk = kp->risk; ep.n_obs = kp->n_obs; ep.alpha = kp->alpha; ep.beta = kp->beta;
+            ep.p_hist = kp->p_hist; ep.C = kp->C; ep.lam = kp->lam; ep.L = kp->L; ep.stage_idx = kp->stage_idx; ep.prefix = kp->prefix;
+            ep.theta = kp->theta; ep.score = kp->score; ep.k_star = kp->k_star; ep.stop = kp->stop; ep.thr_stop = kp->thr_stop;
+            ep.stats = kp->stats;
+            pin_epilogue_params(ep);
+            // The predictor's 2113 packed weights go STRAIGHT into LDS (global_load_lds: no VGPR is held; as registers across the
+            // stream they took this instantiation to 135 VGPRs = one workgroup per CU), issued by the wave that can end up running
+            // the epilogue: the designated finisher's (the sequence's last row; with split rows its last slice).  8 x 1 KiB (W1^T),
+            // then b1 / W2 (64 floats) and b2 as dwords; with them the sequence's feature row, one value per lane.  They fly under
+            // the barrier, the slot fold and finish_row; phase A of the first layer waits for them (vmcnt) -- behind the stream the
+            // chip is quiet and the round trip short.  (Round 3 issued them in front of the stream: see above.)
+#if defined(ASD_LAB) && ASD_LAB == 5   // lab: no weight DMA, no feature load
+            if (false) {
+#else
+            if (fused && k == a_K - 1 && (own_row || split == S - 1)) {
+#endif
+                typedef __attribute__((address_space(3))) void lds_void;
+                typedef const __attribute__((address_space(1))) void glb_void;
+                const char* src = reinterpret_cast<const char*>(ep.packed);
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(src + ps * 1024 + lane * 16), (lds_void*)(reinterpret_cast<char*>(wlds) + ps * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + 8192 + lane * 4), (lds_void*)(reinterpret_cast<char*>(wlds) + 8192), 4, 0, 0);
+                if (lane == 0)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(src + 8192 + 256), (lds_void*)(reinterpret_cast<char*>(wlds) + 8192 + 256), 4, 0, 0);
+                raw_feat = reinterpret_cast<const uint32_t*>(ep.feat)[static_cast<int64_t>(b) * ep.ldf + lane];
+            }
+        }
         float hm = kSentinel, hs = 0.0f, ht = 0.0f;
         if (do_head) {
             const float xv = E::from_raw(raw_head);
@@ -359,7 +451,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     }
     // tile slots -> slice: wave 0 folds slots lane, lane+64, ... in order, then across lanes
     __syncthreads();
-    if (wave != 0) return;
+    if (__builtin_amdgcn_readfirstlane(wave) != 0) return;
     float m2 = kSentinel, s = 0.0f, tsum = 0.0f;
     for (uint32_t t = static_cast<uint32_t>(lane); t <= n_tiles; t += 64) {
         const uint64_t g = stage[t];
@@ -392,26 +484,59 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             // last arriver = two more memory round trips on the tail.)
             float lp = 0.0f;
             bool flag = false;
+            if (lane == 0) flag = finish_row(m2, s, x_tok, c2, lpd, lu_row, lp);
+            uint64_t* slots = reinterpret_cast<uint64_t*>(line + kLpLineOffset);
+            const uint64_t mine = (1ull << 63) | (static_cast<uint64_t>(flag ? 1u : 0u) << 32) | __float_as_uint(lp);
+            if (k != p.K - 1) {
+                if (lane == 0) {   // the hand-off first: it is what the sequence's finisher waits for
+#if defined(ASD_LAB) && ASD_LAB == 4
+                    __hip_atomic_exchange(slots + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+                    if (row + 1 != p.withhold1) __hip_atomic_store(slots + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+                    p.lp_t[row] = lp;
+                    p.accept[row] = flag ? 1 : 0;
+                    if (p.row_max_lp) p.row_max_lp[row] = row_max_logprob(s);
+                }
+                return;
+            }
+            ASD_STAMP_AT(4);
+            // the weight DMA and the feature row were issued behind the stream, a barrier + slot fold + finish_row ago: landed
+            // (nothing younger is outstanding yet, so this wait names exactly them)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_feat) :: "memory");
+            EpiLate late;
+            epi_late_prefetch(ep, b, lane, late);        // the decision inputs: in flight while the slots are polled
+            uint64_t sv = __shfl(mine, 0, 64);              // the finisher's own row (lane K - 1 keeps it)
+#if defined(ASD_LAB) && ASD_LAB == 4
+            if (lane < p.K - 1) sv = __hip_atomic_exchange(slots + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+            if (lane < p.K - 1) sv = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // first probe: issued ...
+#endif
+            // ... and phase A of the predictor's first layer (everything but the five statistics columns) runs under it
+            EpiPhaseA pa;
+            epi_phase_a_lds(ep, lane, __uint_as_float(raw_feat), wlds, reinterpret_cast<float*>(stage + 192), pa);
+            {
+                uint32_t sv_lo = static_cast<uint32_t>(sv), sv_hi = static_cast<uint32_t>(sv >> 32);
+                asm volatile("" : "+v"(pa.h), "+v"(pa.wd[0]), "+v"(pa.wd[1]), "+v"(pa.wd[2]), "+v"(pa.wd[3]), "+v"(pa.wd[4]), "+v"(pa.b1), "+v"(pa.w2),
+                             "+v"(pa.b2), "+v"(sv_lo), "+v"(sv_hi));   // the probe's first use is HERE, behind phase A
+                sv = (static_cast<uint64_t>(sv_hi) << 32) | sv_lo;
+            }
             if (lane == 0) {
-                flag = finish_row(m2, s, x_tok, c2, lpd, lu_row, lp);
                 p.lp_t[row] = lp;
                 p.accept[row] = flag ? 1 : 0;
                 if (p.row_max_lp) p.row_max_lp[row] = row_max_logprob(s);
             }
-            uint64_t* slots = reinterpret_cast<uint64_t*>(line + kLpLineOffset);
-            const uint64_t mine = (1ull << 63) | (static_cast<uint64_t>(flag ? 1u : 0u) << 32) | __float_as_uint(lp);
-            if (k != p.K - 1) {
-                if (lane == 0 && row + 1 != p.withhold1) __hip_atomic_store(slots + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-            ASD_STAMP_AT(4);
-            EpiLate late;
-            epi_late_prefetch(p.epi, b, lane, late);        // feature + decision inputs: in flight while the slots are polled
-            uint64_t sv = __shfl(mine, 0, 64);              // the finisher's own row (lane K - 1 keeps it)
+#if defined(ASD_LAB) && (ASD_LAB == 2 || ASD_LAB == 5)      // lab build (tools/lab_fused_tail.py): no wait for the siblings at all
+            sv = __shfl(mine, 0, 64);
+            if (lane < p.K - 1) __hip_atomic_store(slots + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
             if (lane < p.K - 1) {
-                sv = poll_slot(slots + lane);
+                sv = poll_more(slots + lane, sv);
+#if !(defined(ASD_LAB) && ASD_LAB == 4)   // (lab 4: the exchange that read the slot emptied it)
                 __hip_atomic_store(slots + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // empty again for the next call
+#endif
             }
+#endif
             const bool lost = lane < p.K && sv == 0ull;
             const unsigned long long bal = __ballot(lane < p.K && ((sv >> 32) & 1ull));
             if (lane == 0) {
@@ -422,12 +547,17 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             }
             ASD_STAMP_AT(5);
             if (__ballot(lost) != 0ull) {
-                if (lane == 0) epi_poison(p.epi, b);
+                if (lane == 0) {
+                    epi_poison(ep, b);
+                    report_lost(p.tickets);
+                }
                 return;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the weights (issued at the kernel's start) has landed
-            epi_finish_lds(p.epi, b, lane, __uint_as_float(static_cast<uint32_t>(sv)), p.K, p.epi.stats_col >= 0 || p.epi.stats != nullptr,
-                           wlds, late, reinterpret_cast<double*>(stage), reinterpret_cast<float*>(stage + 192));
+#if defined(ASD_LAB) && (ASD_LAB == 1 || ASD_LAB == 2 || ASD_LAB == 5)   // lab build: no epilogue (what the step costs without it)
+            if (lane == 0 && ep.score) ep.score[b] = pa.h + pa.wd[0] + pa.b1 + pa.w2 + pa.b2 + __uint_as_float(static_cast<uint32_t>(sv));
+            return;
+#endif
+            epi_finish_lds(ep, b, lane, __uint_as_float(static_cast<uint32_t>(sv)), p.K, ep.stats_col >= 0 || ep.stats != nullptr, late, pa);
             ASD_STAMP_AT(8);
             return;
         }
@@ -444,14 +574,22 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             uint64_t* word = reinterpret_cast<uint64_t*>(line + 2);
             const uint64_t mine = (1ull << 32) | (static_cast<uint64_t>(flag ? 1u : 0u) << k);
             ASD_STAMP_AT(4);
+#if defined(ASD_LAB) && ASD_LAB == 4
+            const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
             const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             if (static_cast<uint32_t>(old >> 32) == static_cast<uint32_t>(p.K - 1)) {
                 const uint32_t mask = static_cast<uint32_t>(old | mine);
                 const uint32_t inv = ~mask;
                 const int n = inv ? __builtin_ctz(inv) : 32;
                 p.n_acc[b] = n < p.K ? n : p.K;
                 if (p.bits) p.bits[b] = mask;
+#if defined(ASD_LAB) && ASD_LAB == 4
+                __hip_atomic_exchange(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
                 __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             }
 #ifdef ASD_STAMP
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -480,20 +618,41 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
 
     // ---- designated finisher of sequence b: finish its K rows ------------------------------------
     EpiLate late;
-    if (FUSED) {
-        if (fused) epi_late_prefetch(p.epi, b, lane, late);   // under the polls below
-    }
     const int frow = b * p.K + lane;  // lane <-> draft position
-    bool lost_x = false;
+    // first probes of the K logit slots and of the first 64 granules: issued, then (FUSED) phase A of the predictor's first
+    // layer runs under them
+    if (FUSED) {   // the weight DMA and the feature row (issued behind the stream) have landed; nothing younger is outstanding yet
+        if (fused) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_feat) :: "memory");
+    }
+    uint64_t xv0 = 0ull, gv0 = 0ull;
     if (lane < p.K) {
         if (p.mode == 0) { lpd = p.lp_d[frow]; uu = p.u[frow]; }
-        const uint64_t xv = poll_slot(xslots + lane);
+        xv0 = __hip_atomic_load(xslots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane < KS) gv0 = __hip_atomic_load(region + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    EpiPhaseA pa;
+    if (FUSED) {
+        if (fused) {
+            epi_late_prefetch(ep, b, lane, late);
+            epi_phase_a_lds(ep, lane, __uint_as_float(raw_feat), wlds, reinterpret_cast<float*>(stage + 192), pa);
+            uint32_t a0 = static_cast<uint32_t>(xv0), a1 = static_cast<uint32_t>(xv0 >> 32), g0 = static_cast<uint32_t>(gv0), g1 = static_cast<uint32_t>(gv0 >> 32);
+            asm volatile("" : "+v"(pa.h), "+v"(pa.wd[0]), "+v"(pa.wd[1]), "+v"(pa.wd[2]), "+v"(pa.wd[3]), "+v"(pa.wd[4]), "+v"(pa.b1), "+v"(pa.w2), "+v"(pa.b2),
+                         "+v"(a0), "+v"(a1), "+v"(g0), "+v"(g1));   // the probes' first use: behind phase A
+            xv0 = (static_cast<uint64_t>(a1) << 32) | a0;
+            gv0 = (static_cast<uint64_t>(g1) << 32) | g0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // phase A's scratch (stage + 192 ...) is dead: granules are staged below
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    bool lost_x = false;
+    if (lane < p.K) {
+        const uint64_t xv = poll_more(xslots + lane, xv0);
         __hip_atomic_store(xslots + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lost_x = xv == 0ull;
         x_tok = __uint_as_float(static_cast<uint32_t>(xv));
     }
     for (int g = lane; g < KS; g += 64) {
-        stage[g] = poll_slot(region + g);       // 0 = lost: poisons its row below
+        stage[g] = g == lane ? poll_more(region + g, gv0) : poll_slot(region + g);       // 0 = lost: poisons its row below
         __hip_atomic_store(region + g, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // empty again for the next call
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -510,6 +669,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         }
         if (lost) { fm = NAN; fs = NAN; }       // a slice never arrived: lp_t = NaN, the row is rejected
     }
+    if (__ballot(lost) != 0ull && lane == 0) report_lost(p.tickets);
 
     if (p.mode == 1) {
         if (lane < p.K) {
@@ -532,14 +692,10 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         if (!fused) return;
         // the finisher's lanes hold all K lp_t: the predictor / stop epilogue runs right here (no hand-off at all)
         if (__ballot(lost) != 0ull) {
-            if (lane == 0) epi_poison(p.epi, b);
+            if (lane == 0) epi_poison(ep, b);
             return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the staged granules are dead; `stage` is the epilogue's scratch
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the LDS-DMA of the weights has landed
-        epi_finish_lds(p.epi, b, lane, lp, p.K, p.epi.stats_col >= 0 || p.epi.stats != nullptr, wlds, late,
-                       reinterpret_cast<double*>(stage), reinterpret_cast<float*>(stage + 192));
+        epi_finish_lds(ep, b, lane, lp, p.K, ep.stats_col >= 0 || ep.stats != nullptr, late, pa);
         ASD_STAMP_AT(8);
     }
 }
@@ -747,6 +903,14 @@ ASD_EXPORT int asd_workspace_init(void* workspace, size_t workspace_bytes, void*
     if (!workspace) return ASD_ERR_INVALID_ARG;
     if (!aligned_to(workspace, 256)) return ASD_ERR_WORKSPACE;
     if (hipMemsetAsync(workspace, 0, workspace_bytes, static_cast<hipStream_t>(stream)) != hipSuccess) return ASD_ERR_HIP;
+    return ASD_OK;
+}
+
+ASD_EXPORT int asd_workspace_status(const void* workspace, uint32_t* status_host, void* stream) {
+    if (!workspace || !status_host) return ASD_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(status_host, workspace, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return ASD_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return ASD_ERR_HIP;
     return ASD_OK;
 }
 

@@ -52,7 +52,43 @@ def device_cu_count(device: int = 0) -> int:
 
 
 # ------------------------------------------------------------------------------- verify + accept
-class VerifyWorkspace:
+class LostHandoffError(RuntimeError):
+    """A kernel's bounded wait for a hand-off word of this workspace ran out (ASD_WS_LOST_HANDOFF): the rows / sequences that
+    depended on it came back POISONED (NaN / reject / tok = -1), and the workspace has been re-initialised."""
+
+
+class _StatusWorkspace:
+    """What every hand-off workspace shares (include/asd_hip.h, asd_workspace_status): `buf`, whose first 32-bit word is the
+    sticky status the kernels or into when a bounded poll gives up."""
+
+    buf: torch.Tensor
+    bytes: int
+
+    def reset(self) -> None:
+        B.check("asd_workspace_init", _lib().asd_workspace_init(self.buf.data_ptr(), self.bytes, _stream()))
+
+    @property
+    def status_word(self) -> torch.Tensor:
+        """0-d int32 view of the status word: read it together with whatever the caller synchronises on anyway."""
+        return self.buf[:4].view(torch.int32)[0]
+
+    def status(self) -> int:
+        """Synchronising read of the status word through the C ABI (asd_workspace_status)."""
+        import ctypes as C
+        out = C.c_uint32(0)
+        B.check("asd_workspace_status", _lib().asd_workspace_status(self.buf.data_ptr(), C.addressof(out), _stream()))
+        return int(out.value)
+
+    def check(self) -> None:
+        """Raise LostHandoffError (after re-initialising the workspace) if a hand-off was lost since the last reset."""
+        st = self.status()
+        if st != 0:
+            self.reset()
+            raise LostHandoffError(f"{type(self).__name__}: status 0x{st:x} (a hand-off word never arrived; results poisoned, "
+                                   "workspace re-initialised)")
+
+
+class VerifyWorkspace(_StatusWorkspace):
     """Ticket + granule scratch of asd_verify_accept, zeroed once (asd_workspace_init).
 
     One workspace serves any number of stream-ordered calls with B' <= B, K' <= K; calls that may
@@ -64,7 +100,7 @@ class VerifyWorkspace:
         self.dtype = dtype
         self.bytes = int(_lib().asd_verify_accept_workspace_bytes(B_, K, V, _DTYPE_CODE[dtype]))
         self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device or torch.device("cuda"))
-        B.check("asd_workspace_init", _lib().asd_workspace_init(self.buf.data_ptr(), self.bytes, _stream()))
+        self.reset()
 
     def fits(self, B_: int, K: int) -> bool:
         need = int(_lib().asd_verify_accept_workspace_bytes(B_, K, self.V, _DTYPE_CODE[self.dtype]))

@@ -82,6 +82,20 @@ int asd_device_cu_count(int device);
 size_t asd_verify_accept_workspace_bytes(int B, int K, int V, int dtype);
 int asd_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 
+/* Sticky status of a workspace (verify, residual-sample and draft-sample workspaces alike): its FIRST 32-bit word.  The
+ * kernels hand results across workgroups through self-tagging words of the workspace and wait for them with a bounded poll;
+ * a word that never arrives poisons what depended on it (lp_target = NaN and reject; score = NaN, k* = L - 1, stop = 0;
+ * tok = -1, lp = NaN) -- never a silently wrong value -- and or-s ASD_WS_LOST_HANDOFF into this word.  The word is cleared
+ * only by asd_workspace_init.  A workspace whose status is non-zero MUST be re-initialised before its next use: the late
+ * word was never handed back empty, so the workspace is no longer all-zero between calls.  (The reference's error
+ * convention on this path: log, count, re-raise -- src/serving/pipeline.py:133-136; SURVEY.md section 8b: "return 0 on
+ * success, negative asd_status on error; never throw".  A launch cannot return what its kernel finds out later: the status
+ * word is that return channel.)
+ * asd_workspace_status copies the word to *status_host and WAITS for `stream` (the one synchronising call of this library);
+ * a caller that synchronises anyway may instead read the word from the buffer itself. */
+#define ASD_WS_LOST_HANDOFF 0x1u
+int asd_workspace_status(const void* workspace, uint32_t* status_host /*host, out*/, void* stream);
+
 int asd_verify_accept(const void* logits, int dtype, int64_t ld_row,
                       const int32_t* tok /*[B,K]*/, const float* lp_draft /*[B,K]*/,
                       const float* u /*[B,K]*/, int B, int K, int V,

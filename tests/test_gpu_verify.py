@@ -662,7 +662,15 @@ def test_a_withheld_hand_off_poisons_the_result_instead_of_folding_a_zero(K_, fo
         sc = s.score.cpu().numpy()
         assert np.isnan(sc[bad_b]) and int(s.k_star[bad_b]) == 2 and int(s.stop[bad_b]) == 0
         assert np.isfinite(np.delete(sc, bad_b)).all()
+    # the loss is REPORTED: the workspace's sticky status word (its first 32 bits) says so, through the C ABI and as a tensor view;
+    # nothing else of the workspace is left dirty by this hook (the withheld word was never written)
+    assert ws.status() == K_.B.WS_LOST_HANDOFF and int(ws.status_word) == K_.B.WS_LOST_HANDOFF
+    assert int(ws.buf[4:].count_nonzero()) == 0
+    with pytest.raises(K_.LostHandoffError):
+        ws.check()                                          # raises once and re-initialises the workspace ...
+    ws.check()                                              # ... so that it is clean again
     assert int(ws.buf.count_nonzero()) == 0
     again = K_.verify_accept(lg, tok, lp_d, u, ws)         # the hook is off: the same workspace serves a clean call
     torch.cuda.synchronize()
     assert np.array_equal(again.accept.cpu().numpy(), c["ref"]["accept"])
+    assert ws.status() == 0

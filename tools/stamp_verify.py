@@ -28,13 +28,14 @@ def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
     geom = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 0, 0, -1]
     chain = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    fused = len(sys.argv) > 4 and sys.argv[4] == "fused"
+    fused = len(sys.argv) > 4 and sys.argv[4] in ("fused", "fused2")
+    twice = len(sys.argv) > 4 and sys.argv[4] == "fused2"    # the in-kernel epilogue run twice: cold vs warm instruction cache
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     lib_path = os.path.join(out, "libasd_hip_stamp.so")
     csrc = os.path.join(ROOT, "adaptive-speculative-decoding_amd", "csrc")
-    subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-DASD_STAMP",
-                           "-ffp-contract=off", f"-I{ROOT}/include", f"-I{csrc}", os.path.join(csrc, "verify_accept.hip"),
+    subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-DASD_STAMP", *( ["-DASD_EPI_TWICE"] if twice else []),
+                           "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=11", f"-I{ROOT}/include", f"-I{csrc}", os.path.join(csrc, "verify_accept.hip"),
                            os.path.join(csrc, "api.hip"), os.path.join(csrc, "predictor.hip"), "-o", lib_path])
     lib = C.CDLL(lib_path)
     from asd_amd import kernels as K
@@ -99,14 +100,15 @@ def main():
         live = s[:, 0] > 0
         s = s[live].astype(np.float64)
         t0 = s[:, 0].min()
-        rel = (s[:, [0, 1, 2, 3, 4, 5, 7, 8]] - t0) / 100.0      # us
+        rel = (s[:, [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15]] - t0) / 100.0      # us
         if it >= 2:
             res.append(rel)
             xcc.append(s[:, 6].astype(int))
             waves.append((wv - t0) / 100.0)
     rel = np.concatenate(res)
     names = ["start", "first batch consumed", "stream end", "wg reduced", "before ticket / slot wait", "ticket back / slots read",
-             "first loads issued", "in-kernel epilogue done"]
+             "first loads issued", "in-kernel epilogue done", "epi: statistics done", "epi: both layers done", "epi: sigmoid done",
+             "epi pass 1: statistics", "epi pass 1: layers", "epi pass 1: sigmoid", "epi pass 2 done"]
     print(f"workload {wl}, geometry {geom}, chain {chain}, {len(res)} launches, {rel.shape[0] // len(res)} workgroups each; us from first start")
     for i, n in enumerate(names):
         col = rel[:, i]
@@ -120,6 +122,34 @@ def main():
     ok = rel[:, 5] > 0
     if ok.any():
         print(f"  tail (t5-t2)           p50 {np.median((rel[:, 5] - rel[:, 2])[ok]):7.2f}  max {(rel[:, 5] - rel[:, 2])[ok].max():7.2f}")
+    fin = rel[:, 7] > 0          # finishers: the workgroups that ran the in-kernel epilogue
+    if fused and fin.any():
+        f = rel[fin]
+
+        def seg(name, a, b):
+            d = f[:, b] - f[:, a]
+            print(f"  finisher {name:34s} p50 {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f}")
+        seg("stream end -> wg reduced", 2, 3)
+        seg("wg reduced -> slot wait begins", 3, 4)
+        seg("slot wait (K-1 polls)", 4, 5)
+        if twice:
+            seg("pass 1: slots -> statistics", 5, 11)
+            seg("pass 1: statistics -> both layers", 11, 12)
+            seg("pass 1: layers -> sigmoid", 12, 13)
+            seg("pass 1: sigmoid -> decided+stored", 13, 7)
+            seg("pass 1 total", 5, 7)
+            seg("pass 2: -> statistics", 7, 8)
+            seg("pass 2: statistics -> both layers", 8, 9)
+            seg("pass 2: layers -> sigmoid", 9, 10)
+            seg("pass 2: sigmoid -> decided+stored", 10, 14)
+            seg("pass 2 total", 7, 14)
+        else:
+            seg("epi: slots -> statistics", 5, 8)
+            seg("epi: statistics -> both layers", 8, 9)
+            seg("epi: layers -> sigmoid", 9, 10)
+            seg("epi: sigmoid -> decided+stored", 10, 7)
+            seg("epi total", 5, 7)
+        seg("stream end -> all done", 2, 14 if twice else 7)
 
 
     w = np.concatenate(waves)
