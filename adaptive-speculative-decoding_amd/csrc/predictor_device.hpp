@@ -489,13 +489,38 @@ __device__ __forceinline__ void epi_finish(const FusedParams& p, int b, int lane
 // kernel's start: no register is held across the stream); the decision inputs are loaded LATE -- issued by the finisher right
 // before it waits for the hand-off slots, i.e. under a wait that is there anyway -- and phase A of the first layer runs under
 // that wait too (epi_phase_a_lds).  Same operations in the same order as epi_finish: bit-identical scores.
-struct EpiLate {
-    float xv;
-    DecidePrefetch d;      // lane 0 only
-};
-__device__ __forceinline__ void epi_late_prefetch(const FusedParams& p, int b, int lane, EpiLate& e) {
-    if (lane == 0) decide_prefetch(p, b, e.d);
+constexpr int kEpiInKernelMaxK = 16;   // draft lengths the in-kernel epilogue takes: its statistics are the DPP form (one row of 16 lanes)
+// The decision inputs of the in-kernel epilogue (the sequence's p_hist row, the stage costs, theta[stage]): 9 doubles that lane 0
+// needs at the very end.  As registers (round 3: DecidePrefetch, issued before the hand-off wait) they are 18 VGPRs live across
+// the statistics -- the register peak of k_verify<FUSED>, which has to stay within 64 for four workgroups per CU at B = 128 -- so
+// they go to LDS by DMA instead (global_load_lds, one dword per lane, three instructions, no VGPR), issued under the hand-off wait,
+// and are read back when the score exists (the compiler orders the read behind the DMA: vmcnt counts in order).
+// dl: kEpiDecideLds doubles of LDS.
+constexpr int kEpiDecideLds = 12;   // [0,4) p_hist row, [4,8) C, [8] theta[stage]
+__device__ __forceinline__ void epi_decide_dma(const FusedParams& p, int b, int lane, double* dl) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    const int n_dp = p.prefix ? p.stage_idx + 1 : p.L;            // <= kDecidePrefetch (launcher)
+    if (p.p_hist && (p.k_star || p.stop) && lane < 2 * n_dp) {
+        __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(p.p_hist + static_cast<int64_t>(b) * p.L) + lane * 4),
+                                         (lds_void*)reinterpret_cast<char*>(dl), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(p.C) + lane * 4),
+                                         (lds_void*)(reinterpret_cast<char*>(dl) + 32), 4, 0, 0);
+    }
+    if (p.theta && p.thr_stop && lane < 2)
+        __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(p.theta + p.stage_idx) + lane * 4),
+                                         (lds_void*)(reinterpret_cast<char*>(dl) + 64), 4, 0, 0);
 }
+// lane 0: the registers decide_and_store_small reads (stages beyond the hierarchy's depth hold whatever the LDS held: unused)
+__device__ __forceinline__ void epi_decide_from_lds(const double* dl, DecidePrefetch& d) {
+#pragma unroll
+    for (int i = 0; i < kDecidePrefetch; ++i) {
+        d.ph[i] = dl[i];
+        d.cc[i] = dl[kDecidePrefetch + i];
+    }
+    d.theta = dl[2 * kDecidePrefetch];
+}
+
 // what phase A leaves in registers for the rest: its accumulator and every weight the steps behind the statistics read (the
 // deferred columns', b1, W2, b2), fetched from LDS NOW so that no LDS round trip stands behind the hand-off
 struct EpiPhaseA {
@@ -521,10 +546,10 @@ __device__ __forceinline__ void epi_phase_a_lds(const FusedParams& p, int lane, 
 }
 // a: epi_phase_a_lds's result
 __device__ __forceinline__ void epi_finish_lds(const FusedParams& p, int b, int lane, float lpv, int n, bool want_stats,
-                                               const EpiLate& e, const EpiPhaseA& a) {
+                                               const double* decide_lds, const EpiPhaseA& a) {
     double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (want_stats) {
-        wave_logprob_stats_regs(lpv, n, lane, st);
+        wave_logprob_stats_row16(lpv, n, lane, st);      // n <= kEpiInKernelMaxK (the launcher sends longer drafts down the two-launch route)
         if (p.stats && lane == 0) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
@@ -533,7 +558,11 @@ __device__ __forceinline__ void epi_finish_lds(const FusedParams& p, int b, int 
     ASD_EPI_STAMP(9);    // statistics done
     const float sc = epi_score(p, lane, a.h, [&](int d) { return a.wd[d]; }, st, want_stats && p.stats_col >= 0, a.b1, a.w2, a.b2);
     ASD_EPI_STAMP(11);   // sigmoid done
-    if (lane == 0) decide_and_store_small(p, b, sc, e.d);
+    if (lane == 0) {
+        DecidePrefetch d;
+        epi_decide_from_lds(decide_lds, d);
+        decide_and_store_small(p, b, sc, d);
+    }
 }
 
 }  // namespace asd

@@ -118,34 +118,11 @@ __device__ __forceinline__ uint64_t poll_slot(uint64_t* slot) {
 
 // the rest of a poll whose first probe `v` was issued earlier (work was placed under it)
 __device__ __forceinline__ uint64_t poll_more(uint64_t* slot, uint64_t v) {
-#if defined(ASD_LAB) && ASD_LAB == 3      // lab: four probes in flight, ~0.15 us apart, each checked as it returns
-    for (int spins = 0; v == 0ull && spins < kSpinLimit; spins += 4) {
-        const uint64_t a = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_sleep(4);
-        const uint64_t b = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_sleep(4);
-        const uint64_t c = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_sleep(4);
-        const uint64_t d = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a != 0ull) { v = a; break; }
-        if (b != 0ull) { v = b; break; }
-        if (c != 0ull) { v = c; break; }
-        v = d;
-    }
-    return v;
-#elif defined(ASD_LAB) && ASD_LAB == 4    // lab: the siblings share this XCD -- read-and-clear in its L2 (workgroup-scope RMW)
-    for (int spins = 0; v == 0ull && spins < kSpinLimit; ++spins) {
-        __builtin_amdgcn_s_sleep(1);
-        v = __hip_atomic_exchange(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    return v;
-#else
     for (int spins = 0; v == 0ull && spins < kSpinLimit; ++spins) {
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return v;
-#endif
 }
 
 // A hand-off word that never arrived poisons its row / sequence AND is reported: the workspace's first word (the unused u32 at
@@ -174,11 +151,22 @@ constexpr int kKernargParamsOffset = 48;
 static_assert(alignof(VerifyParams) == 8, "kKernargParamsOffset assumes an 8-byte aligned parameter struct");
 // an opaque definition of a wave-uniform value: whatever is derived from it below cannot be re-loaded from the kernarg segment
 #define ASD_PIN(x) asm volatile("" : "+s"(x))
+// ... and for a pointer: its bits are pinned, then turned back into a GLOBAL pointer.  A pointer that comes out of an asm (or out
+// of a hand-written load of the kernarg segment) is a generic pointer to the compiler, and what it dereferences becomes flat_load /
+// flat_store -- which count on lgkmcnt as well as vmcnt, i.e. every wait for an LDS operation also waits for them (two such loads
+// in front of the tile loop, whose tile claims are LDS atomics, cost the whole kernel 1 us: profiles/r04_lab_flat_loads.json).
+template <typename T>
+__device__ __forceinline__ T* pin_global_ptr(T* p) {
+    uint64_t bits = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+s"(bits));
+    return (T*)(__attribute__((address_space(1))) T*)bits;     // integer -> GLOBAL pointer (-> generic, which the compiler sees through)
+}
+#define ASD_PIN_PTR(x) do { x = pin_global_ptr(x); } while (0)
 __device__ __forceinline__ void pin_epilogue_params(FusedParams& e) {
-    ASD_PIN(e.K); ASD_PIN(e.feat); ASD_PIN(e.ldf); ASD_PIN(e.stats_col); ASD_PIN(e.packed);
+    ASD_PIN(e.K); ASD_PIN_PTR(e.feat); ASD_PIN(e.ldf); ASD_PIN(e.stats_col); ASD_PIN_PTR(e.packed);
     ASD_PIN(e.risk); ASD_PIN(e.n_obs); ASD_PIN(e.alpha); ASD_PIN(e.beta);
-    ASD_PIN(e.p_hist); ASD_PIN(e.C); ASD_PIN(e.lam); ASD_PIN(e.L); ASD_PIN(e.stage_idx); ASD_PIN(e.prefix);
-    ASD_PIN(e.theta); ASD_PIN(e.score); ASD_PIN(e.k_star); ASD_PIN(e.stop); ASD_PIN(e.thr_stop); ASD_PIN(e.stats);
+    ASD_PIN_PTR(e.p_hist); ASD_PIN_PTR(e.C); ASD_PIN(e.lam); ASD_PIN(e.L); ASD_PIN(e.stage_idx); ASD_PIN(e.prefix);
+    ASD_PIN_PTR(e.theta); ASD_PIN_PTR(e.score); ASD_PIN_PTR(e.k_star); ASD_PIN_PTR(e.stop); ASD_PIN_PTR(e.thr_stop); ASD_PIN_PTR(e.stats);
 }
 
 template <int DT, int UNROLL, bool CHECK, bool STATS>
@@ -228,6 +216,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     __shared__ __attribute__((aligned(16))) uint64_t stage[kMaxStage];   // tile slots while streaming, then scratch of the finisher
     __shared__ float stage_t[STATS ? kMaxStage : 1];                      // STATS: the tiles' third value
     __shared__ __attribute__((aligned(16))) float wlds[FUSED ? 64 * 32 + 68 : 4];   // FUSED: the predictor's packed weights (LDS-DMA)
+    __shared__ __attribute__((aligned(16))) double dlds[FUSED ? kEpiDecideLds : 1];  // FUSED: the decision inputs (LDS-DMA)
 
     ASD_STAMP_AT(0);
 #ifdef ASD_STAMP
@@ -241,11 +230,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     const float c2 = a_scale2;
     // grid = (rows, splits): no division stands between the wave's start and its first loads (as a 1-D grid the prologue
     // held three 64-bit and one 32-bit software divisions -- ~570 scalar instructions, ~2.8 us in the stamped build)
-#if defined(ASD_LAB) && ASD_LAB == 4      // lab: workgroup i runs on XCD i % 8 -- give every XCD a contiguous run of rows (whole sequences)
-    const int row = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-#else
     const int row = static_cast<int>(blockIdx.x);
-#endif
     const int split = static_cast<int>(blockIdx.y);
 
     const char* rowp = static_cast<const char*>(a_logits) + static_cast<int64_t>(row) * a_ld_row * E::kBytes;
@@ -324,11 +309,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     if (do_tail) raw_tail = E::raw(rowp, static_cast<int64_t>(head) + static_cast<int64_t>(nvec) * E::kPerVec + (lane - 32));
     const int b = static_cast<int>(static_cast<uint32_t>(row) / static_cast<uint32_t>(a_K));
     const int k = row - b * a_K;
-#if defined(ASD_LAB) && ASD_LAB == 7   // lab: the FUSED instantiation run as the plain kernel (its static cost alone)
-    const bool fused = FUSED && p.mode == 7;
-#else
     const bool fused = FUSED && p.mode == 0;   // one workgroup per row: the sequence's designated finisher; split rows: the last arriver
-#endif
 #define ASD_CLAIM(dst)                                                                                   \
     do {                                                                                                 \
         uint32_t c_ = 0;                                                                                 \
@@ -489,11 +470,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             const uint64_t mine = (1ull << 63) | (static_cast<uint64_t>(flag ? 1u : 0u) << 32) | __float_as_uint(lp);
             if (k != p.K - 1) {
                 if (lane == 0) {   // the hand-off first: it is what the sequence's finisher waits for
-#if defined(ASD_LAB) && ASD_LAB == 4
-                    __hip_atomic_exchange(slots + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
                     if (row + 1 != p.withhold1) __hip_atomic_store(slots + k, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
                     p.lp_t[row] = lp;
                     p.accept[row] = flag ? 1 : 0;
                     if (p.row_max_lp) p.row_max_lp[row] = row_max_logprob(s);
@@ -504,14 +481,8 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             // the weight DMA and the feature row were issued behind the stream, a barrier + slot fold + finish_row ago: landed
             // (nothing younger is outstanding yet, so this wait names exactly them)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_feat) :: "memory");
-            EpiLate late;
-            epi_late_prefetch(ep, b, lane, late);        // the decision inputs: in flight while the slots are polled
             uint64_t sv = __shfl(mine, 0, 64);              // the finisher's own row (lane K - 1 keeps it)
-#if defined(ASD_LAB) && ASD_LAB == 4
-            if (lane < p.K - 1) sv = __hip_atomic_exchange(slots + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
             if (lane < p.K - 1) sv = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // first probe: issued ...
-#endif
             // ... and phase A of the predictor's first layer (everything but the five statistics columns) runs under it
             EpiPhaseA pa;
             epi_phase_a_lds(ep, lane, __uint_as_float(raw_feat), wlds, reinterpret_cast<float*>(stage + 192), pa);
@@ -521,6 +492,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
                              "+v"(pa.b2), "+v"(sv_lo), "+v"(sv_hi));   // the probe's first use is HERE, behind phase A
                 sv = (static_cast<uint64_t>(sv_hi) << 32) | sv_lo;
             }
+            epi_decide_dma(ep, b, lane, dlds);           // the decision inputs (p_hist row, stage costs, theta) -> LDS while the slots are polled
             if (lane == 0) {
                 p.lp_t[row] = lp;
                 p.accept[row] = flag ? 1 : 0;
@@ -532,9 +504,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
 #else
             if (lane < p.K - 1) {
                 sv = poll_more(slots + lane, sv);
-#if !(defined(ASD_LAB) && ASD_LAB == 4)   // (lab 4: the exchange that read the slot emptied it)
                 __hip_atomic_store(slots + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // empty again for the next call
-#endif
             }
 #endif
             const bool lost = lane < p.K && sv == 0ull;
@@ -557,7 +527,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             if (lane == 0 && ep.score) ep.score[b] = pa.h + pa.wd[0] + pa.b1 + pa.w2 + pa.b2 + __uint_as_float(static_cast<uint32_t>(sv));
             return;
 #endif
-            epi_finish_lds(ep, b, lane, __uint_as_float(static_cast<uint32_t>(sv)), p.K, ep.stats_col >= 0 || ep.stats != nullptr, late, pa);
+            epi_finish_lds(ep, b, lane, __uint_as_float(static_cast<uint32_t>(sv)), p.K, ep.stats_col >= 0 || ep.stats != nullptr, dlds, pa);
             ASD_STAMP_AT(8);
             return;
         }
@@ -574,22 +544,14 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             uint64_t* word = reinterpret_cast<uint64_t*>(line + 2);
             const uint64_t mine = (1ull << 32) | (static_cast<uint64_t>(flag ? 1u : 0u) << k);
             ASD_STAMP_AT(4);
-#if defined(ASD_LAB) && ASD_LAB == 4
-            const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
             const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
             if (static_cast<uint32_t>(old >> 32) == static_cast<uint32_t>(p.K - 1)) {
                 const uint32_t mask = static_cast<uint32_t>(old | mine);
                 const uint32_t inv = ~mask;
                 const int n = inv ? __builtin_ctz(inv) : 32;
                 p.n_acc[b] = n < p.K ? n : p.K;
                 if (p.bits) p.bits[b] = mask;
-#if defined(ASD_LAB) && ASD_LAB == 4
-                __hip_atomic_exchange(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
                 __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
             }
 #ifdef ASD_STAMP
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -617,7 +579,6 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     if (k != p.K - 1 || split != S - 1) return;
 
     // ---- designated finisher of sequence b: finish its K rows ------------------------------------
-    EpiLate late;
     const int frow = b * p.K + lane;  // lane <-> draft position
     // first probes of the K logit slots and of the first 64 granules: issued, then (FUSED) phase A of the predictor's first
     // layer runs under them
@@ -633,13 +594,13 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     EpiPhaseA pa;
     if (FUSED) {
         if (fused) {
-            epi_late_prefetch(ep, b, lane, late);
             epi_phase_a_lds(ep, lane, __uint_as_float(raw_feat), wlds, reinterpret_cast<float*>(stage + 192), pa);
             uint32_t a0 = static_cast<uint32_t>(xv0), a1 = static_cast<uint32_t>(xv0 >> 32), g0 = static_cast<uint32_t>(gv0), g1 = static_cast<uint32_t>(gv0 >> 32);
             asm volatile("" : "+v"(pa.h), "+v"(pa.wd[0]), "+v"(pa.wd[1]), "+v"(pa.wd[2]), "+v"(pa.wd[3]), "+v"(pa.wd[4]), "+v"(pa.b1), "+v"(pa.w2), "+v"(pa.b2),
                          "+v"(a0), "+v"(a1), "+v"(g0), "+v"(g1));   // the probes' first use: behind phase A
             xv0 = (static_cast<uint64_t>(a1) << 32) | a0;
             gv0 = (static_cast<uint64_t>(g1) << 32) | g0;
+            epi_decide_dma(ep, b, lane, dlds);      // the decision inputs -> LDS, under the polls below
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // phase A's scratch (stage + 192 ...) is dead: granules are staged below
             __builtin_amdgcn_wave_barrier();
         }
@@ -662,6 +623,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     float fm = kSentinel, fs = 0.0f;
     bool lost = lost_x;
     if (lane < p.K) {
+#pragma unroll 4      // (the compiler's own choice, 8, takes the FUSED instantiation past 64 VGPRs: phase A's results are live here)
         for (int j = 0; j < S; ++j) {
             const uint64_t g = stage[lane * S + j];
             lost = lost || g == 0ull;
@@ -695,7 +657,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             if (lane == 0) epi_poison(ep, b);
             return;
         }
-        epi_finish_lds(ep, b, lane, lp, p.K, ep.stats_col >= 0 || ep.stats != nullptr, late, pa);
+        epi_finish_lds(ep, b, lane, lp, p.K, ep.stats_col >= 0 || ep.stats != nullptr, dlds, pa);
         ASD_STAMP_AT(8);
     }
 }
@@ -984,10 +946,11 @@ ASD_EXPORT int asd_verify_accept_fused_ex(const void* logits, int dtype, int64_t
     Geometry g;
     const int rc0 = unpack_options(opt, p.scale2, g);
     if (rc0 != ASD_OK) return rc0;
-    // the in-kernel epilogue is the reference's 64 -> 32 -> 1 predictor over a hierarchy of <= 4 tiers (the reference's: 3 or 4)
-    // at the heuristic's geometries; any other predictor shape, depth or forced geometry gets the same results from two launches
+    // the in-kernel epilogue is the reference's 64 -> 32 -> 1 predictor over a hierarchy of <= 4 tiers (the reference's: 3 or 4),
+    // draft lengths <= 16, at the heuristic's geometries; any other predictor shape, depth, draft length or forced geometry gets the
+    // same results from two launches
     const bool geometry_ok = (g.threads == 0 || g.threads == 512) && (g.unroll == 0 || g.unroll == 2 || g.unroll == 3);
-    const bool in_kernel = in_dim == 64 && hidden == 32 && geometry_ok && L <= kDecidePrefetch;
+    const bool in_kernel = in_dim == 64 && hidden == 32 && geometry_ok && L <= kDecidePrefetch && K <= kEpiInKernelMaxK;
     if (!in_kernel) {
         const int rc = asd_verify_accept_ex(logits, dtype, ld_row, tok, lp_draft, u, B, K, V, lp_target, accept, n_acc,
                                             accept_bits, workspace, workspace_bytes, opt, stream);

@@ -26,12 +26,16 @@ import torch  # noqa: E402
 from bench import N_STAGES, STAGE_COSTS, WORKLOADS, build_inputs, predictor_weights  # noqa: E402
 
 
+# variants >= 20 are the product code (ASD_LAB = 0) under other build switches
+SWITCHES = {20: ["-DASD_PARAMS_EARLY=1"], 21: ["-DASD_PARAMS_EARLY=0"]}
+
+
 def build_variant(n: int) -> str:
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     lib_path = os.path.join(out, f"libasd_hip_lab{n}.so")
     csrc = os.path.join(ROOT, "adaptive-speculative-decoding_amd", "csrc")
-    subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", f"-DASD_LAB={n}",
+    subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", f"-DASD_LAB={0 if n >= 20 else n}", *SWITCHES.get(n, []),
                            "-fno-fast-math", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=11", f"-I{ROOT}/include", f"-I{csrc}",
                            os.path.join(csrc, "verify_accept.hip"), os.path.join(csrc, "api.hip"), os.path.join(csrc, "predictor.hip"),
                            "-o", lib_path])
@@ -45,6 +49,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--reps", type=int, default=300)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "lab_fused_tail.json"))
+    ap.add_argument("--extra-libs", default="", help="name=path,... : prebuilt libraries (e.g. an older commit's build) timed in the same process")
     a = ap.parse_args()
     from asd_amd import kernels as K
     from asd_amd._binding import SIGNATURES
@@ -71,8 +76,18 @@ def main():
         fns[f"fused/{n}"] = ("fused", ff)
         if n == variants[0]:
             fns["plain"] = ("plain", pl)
-        elif n == 4:
-            fns["plain/4"] = ("plain", pl)
+        elif n == 4 or n >= 20:
+            fns[f"plain/{n}"] = ("plain", pl)
+
+    for item in [x for x in a.extra_libs.split(",") if x]:
+        name, path = item.split("=")
+        lib = C.CDLL(path if os.path.isabs(path) else os.path.join(ROOT, path))
+        ff = lib.asd_verify_accept_fused_ex
+        ff.restype, ff.argtypes = SIGNATURES["asd_verify_accept_fused_ex"]
+        pl = lib.asd_verify_accept_ex
+        pl.restype, pl.argtypes = SIGNATURES["asd_verify_accept_ex"]
+        fns[f"fused@{name}"] = ("fused", ff)
+        fns[f"plain@{name}"] = ("plain", pl)
 
     def launch(kind, fn, j):
         bj = bufs[j % nbuf]
@@ -109,7 +124,7 @@ def main():
     ref = {}
     checks = {}
     for name, (kind, fn) in fns.items():
-        n = int(name.split("/")[1]) if "/" in name else variants[0]
+        n = int(name.split("/")[1]) if "/" in name else (0 if "@" in name else variants[0])
         o = bufs[0]["out"]
         for t in (o.lp_target, o.accept, o.n_acc, score, ks):
             t.zero_()
@@ -121,7 +136,7 @@ def main():
             got["k_star"] = ks.cpu().numpy().copy()
         if not ref:
             ref = got
-        if n in (0, 3, 4):
+        if n in (0, 3, 4) or n >= 20:
             checks[name] = all(np.array_equal(ref[k], got[k], equal_nan=True) for k in got if k in ref)
             if not checks[name]:
                 for k in got:
