@@ -306,13 +306,18 @@ class LinearWorkspace:
     """Slab buffer of asd_linear's reduction slices; grows to the largest (M, N, D) it has served.  One per stream:
     consecutive calls on a stream may share it."""
 
-    def __init__(self, device):
+    def __init__(self, device, on_grow=None):
+        """on_grow: called BEFORE the buffer is replaced by a larger one -- whoever captured hipGraphs that hold the old
+        buffer's address (SyntheticLM.enable_graphs) must drop them."""
         self.device = torch.device(device)
         self.buf: Optional[torch.Tensor] = None
+        self.on_grow = on_grow
 
     def ensure(self, M: int, N: int, D: int) -> Tuple[int, int]:
         need = int(_lib().asd_linear_workspace_bytes(M, N, D))
         if self.buf is None or self.buf.numel() < need:
+            if self.buf is not None and self.on_grow is not None:
+                self.on_grow()
             self.buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
         return self.buf.data_ptr(), self.buf.numel()
 

@@ -539,6 +539,7 @@ class HierarchyTrace:
     fed_tokens: List[int] = field(default_factory=list)      # model positions each verify tier computed
     records: List[dict] = field(default_factory=list)        # per step (keep_inputs)
     bytes_sent: Dict[str, int] = field(default_factory=dict)
+    messages_sent: Dict[str, int] = field(default_factory=dict)     # backend calls per message name (one per message and destination)
     rows_shipped: int = 0
     tier_forwards: List[int] = field(default_factory=list)   # model forward passes per tier (tier 0: K per step)
     tier_forward_positions: List[int] = field(default_factory=list)   # sequence-positions those passes computed
@@ -639,7 +640,10 @@ class Placement:
 
 class Wire:
     """Point-to-point movement of the fixed-shape messages between roles; roles that share a rank hand the
-    tensors over directly.  Counts the bytes that really crossed a link.
+    tensors over directly.  ONE backend call per (message, destination): the tensors of a message are packed into one
+    byte buffer (each segment padded to 8 bytes) -- over RCCL every send / recv is a kernel launch of its own, and on
+    first use between two ranks also the lazy construction of their point-to-point communicator, which `warm_up`
+    therefore forces before the first timed step.  Counts the bytes and the messages that really crossed a link.
 
     loopback=True (tests, one GPU): a message between two roles of the SAME rank also goes through the backend --
     one grouped isend + irecv of the rank to itself (ncclSend / ncclRecv inside one ncclGroup on RCCL) -- instead of the
@@ -651,29 +655,66 @@ class Wire:
         self.staged = dist.is_initialized() and host_staged(group) and torch.device(device).type == "cuda"
         self.loopback = bool(loopback) and dist.is_initialized()
         self.local: Dict[Tuple[str, int, int], List[torch.Tensor]] = {}
-        self.bytes: Dict[str, int] = {}
+        self.bytes: Dict[str, int] = {}          # name -> bytes handed to the backend (padding included)
+        self.messages: Dict[str, int] = {}       # name -> backend calls (one per message and destination)
 
-    def _to_wire(self, t: torch.Tensor) -> torch.Tensor:
-        t = t.contiguous()
-        return t.cpu() if (t.is_cuda and self.staged) else t
+    # ---- packing: [tensor, ...] <-> one uint8 buffer
+    @staticmethod
+    def _seg(numel: int, esz: int) -> int:
+        return (numel * esz + 7) // 8 * 8
+
+    def _pack(self, tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+        total = sum(self._seg(t.numel(), t.element_size()) for t in tensors)
+        dev = tensors[0].device if tensors else self.device
+        buf = torch.zeros((total,), dtype=torch.uint8, device=dev)
+        o = 0
+        for t in tensors:
+            n = t.numel() * t.element_size()
+            if n:
+                buf[o:o + n] = t.contiguous().reshape(-1).view(torch.uint8)
+            o += self._seg(t.numel(), t.element_size())
+        return buf
+
+    def _unpack(self, buf: torch.Tensor, like: Sequence[Tuple[Tuple[int, ...], torch.dtype]]) -> List[torch.Tensor]:
+        out, o = [], 0
+        for shape, dtype in like:
+            numel = int(np.prod(shape)) if len(shape) else 1
+            esz = torch.empty((), dtype=dtype).element_size()
+            n = numel * esz
+            t = buf[o:o + n].clone().view(dtype).reshape(shape) if n else torch.empty(shape, dtype=dtype, device=buf.device)
+            out.append(t.to(self.device))
+            o += self._seg(numel, esz)
+        return out
+
+    def _like_of(self, tensors: Sequence[torch.Tensor]):
+        return [(tuple(t.shape), t.dtype) for t in tensors]
+
+    def _count(self, name: str, nbytes: int) -> None:
+        self.bytes[name] = self.bytes.get(name, 0) + nbytes
+        self.messages[name] = self.messages.get(name, 0) + 1
 
     def send(self, name: str, tensors: Sequence[torch.Tensor], src: int, dsts: Sequence[int]) -> None:
         if self.rank != src:
             return
+        buf = None
         for d in dsts:
             if d == src:
                 self.local[(name, src, d)] = list(tensors)
                 continue
-            for t in tensors:
-                t = self._to_wire(t)
-                if t.numel():
-                    dist.send(t, dst=d, group=self.group)
-                    self.bytes[name] = self.bytes.get(name, 0) + t.numel() * t.element_size()
+            if buf is None:
+                buf = self._pack(tensors)
+                if buf.is_cuda and self.staged:
+                    buf = buf.cpu()
+            if buf.numel():
+                dist.send(buf, dst=d, group=self.group)
+                self._count(name, buf.numel())
 
-    def _through_backend(self, name: str, t: torch.Tensor) -> torch.Tensor:
-        if not t.numel():
-            return t
-        src = self._to_wire(t)
+    def _through_backend(self, name: str, tensors: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        src = self._pack(tensors)
+        if not src.numel():
+            return list(tensors)
+        if src.is_cuda and self.staged:
+            src = src.cpu()
         if host_staged(self.group):             # gloo has no pair of a rank with itself: the host staging alone
             dst = src.clone()
         else:
@@ -682,24 +723,58 @@ class Wire:
             for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, me, self.group),
                                              dist.P2POp(dist.irecv, dst, me, self.group)]):
                 w.wait()
-        key = name + " (loopback)"
-        self.bytes[key] = self.bytes.get(key, 0) + src.numel() * src.element_size()
-        return dst.to(self.device)
+        self._count(name + " (loopback)", src.numel())
+        return self._unpack(dst, self._like_of(tensors))
 
     def recv(self, name: str, like: Sequence[Tuple[Tuple[int, ...], torch.dtype]], src: int) -> List[torch.Tensor]:
         if self.rank == src:
             got = self.local.pop((name, src, src))
             if self.loopback:
-                got = [self._through_backend(name, t) for t in got]
+                got = self._through_backend(name, got)
             return got
-        out = []
-        for shape, dtype in like:
-            dev = "cpu" if self.staged else self.device
-            t = torch.empty(shape, dtype=dtype, device=dev)
-            if t.numel():
-                dist.recv(t, src=src, group=self.group)
-            out.append(t.to(self.device))
-        return out
+        total = sum(self._seg(int(np.prod(shape)) if len(shape) else 1, torch.empty((), dtype=dtype).element_size())
+                    for shape, dtype in like)
+        buf = torch.empty((total,), dtype=torch.uint8, device="cpu" if self.staged else self.device)
+        if total:
+            dist.recv(buf, src=src, group=self.group)
+        return self._unpack(buf, like)
+
+    def warm_up(self, pairs: Sequence[Tuple[int, int]]) -> None:
+        """One 8-byte message over every (src, dst) pair the loop will use, in the given order (the same on every rank), so
+        that the backend's per-pair state -- RCCL builds a point-to-point communicator on first use -- exists before the
+        first timed step.  Not counted in `bytes` / `messages`."""
+        if not dist.is_initialized():
+            return
+        for a, b in pairs:
+            if a == b:
+                continue
+            t = torch.zeros((8,), dtype=torch.uint8, device="cpu" if (self.staged or torch.device(self.device).type == "cpu") else self.device)
+            if self.rank == a:
+                dist.send(t, dst=b, group=self.group)
+            elif self.rank == b:
+                dist.recv(t, src=a, group=self.group)
+
+
+def placement_pairs(placement: "Placement", L: int) -> List[Tuple[int, int]]:
+    """Every (src, dst) rank pair run_hierarchical_rank sends over, in a fixed order."""
+    D = placement.draft
+    verify_ranks = sorted({r for t in placement.tiers for r in t})
+    everyone = sorted({D} | set(verify_ranks))
+    pairs: List[Tuple[int, int]] = []
+
+    def add(a, b):
+        if a != b and (a, b) not in pairs:
+            pairs.append((a, b))
+    for r in verify_ranks:
+        add(D, r)                                            # draft, rows
+    for s in range(1, L):
+        add(placement.leader(s), D)                          # verdict, drawn
+        if s > 1:
+            for r in placement.ranks_of(s):
+                add(placement.leader(s - 1), r)              # escalate
+    for r in everyone:
+        add(D, r)                                            # final
+    return pairs
 
 
 @torch.no_grad()
@@ -727,6 +802,13 @@ def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[Draft
     tr = HierarchyTrace(state.tokens, state.seq_len, tier_counts=[0] * L, tier_calls=[0] * L)
     limit = max_steps if max_steps is not None else cap + 4
     i32, f32, f64, u8 = torch.int32, torch.float32, torch.float64, torch.uint8
+    if state.steps == 0:                      # the first call on these roles: per-pair backend state before any timed step
+        wire.warm_up(placement_pairs(placement, L))
+    if controller is not None and len(placement.ranks_of(controller.s)) != 1:
+        # lambda changes on the controller tier's leader only (nothing is broadcast): a tier whose verdict is computed on
+        # several ranks (vocab shards) would then decide stop-or-escalate from different lambdas and desynchronise the wire
+        raise ValueError(f"the lambda controller's tier ({controller.s}) is placed on {len(placement.ranks_of(controller.s))} ranks; "
+                         "it must be a single-rank tier")
     while tr.steps < limit:
         # ---- tier 0 proposes; the block goes to every rank that hosts a verify tier
         dm = None
@@ -808,6 +890,7 @@ def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[Draft
     tr.tier_forwards = [draft.fwd_calls if draft is not None else 0] + [tiers[s].fwd_calls if s in tiers else 0 for s in range(1, L)]
     tr.tier_forward_positions = [draft.fwd_positions if draft is not None else 0] + tr.fed_tokens
     tr.bytes_sent = dict(wire.bytes)
+    tr.messages_sent = dict(wire.messages)
     return tr
 
 
@@ -816,7 +899,7 @@ def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: Hie
                      max_new_tokens: int, predictor, ops=None, dtype: torch.dtype = torch.bfloat16,
                      heads: Sequence[str] = ("logits", "fused"), logit_scale: float = 1.0, seeds: Sequence[int] = (1, 2, 3),
                      keep_inputs: bool = False, weight_noise: Sequence[float] = (0.0, 0.0, 0.0), share_seed: Optional[int] = None,
-                     hip_layers: Optional[bool] = None, pack_weights: bool = False
+                     hip_layers: Optional[bool] = None, pack_weights: bool = False, backend: Optional[str] = None
                      ) -> Tuple[Optional[DraftRole], Dict[int, VerifyRole]]:
     """The roles `rank` hosts under `placement`: tier 0 + verify tiers, models built on prompt_ids.device.
     shapes: one synthetic_lm.LMShape per tier.  heads[s-1]: "logits" (lm_head GEMM + asd_verify_accept), "fused"
@@ -826,7 +909,9 @@ def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: Hie
     that agree often enough to accept tokens.
     hip_layers: run the models' passes through asd_decoder_forward (serving/hip_decoder.py) instead of torch modules.  None:
     wherever the stack supports the model (CUDA, bf16, head_dim 128 -- every Qwen2.5 shape); True: required (raises
-    otherwise); False: torch modules.  `model.execution` on every role's model says which one it got."""
+    otherwise); False: torch modules.  `model.execution` on every role's model says which one it got.
+    backend: the backend of the process group a vocab-sharded tier creates ("nccl" when the job's default group is a gloo
+    control group and the data path is RCCL); None = the default group's."""
     from .synthetic_lm import SyntheticLM
     ops = ops if ops is not None else HipOps()
     dev = prompt_ids.device
@@ -836,7 +921,11 @@ def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: Hie
     def make(i):
         m = SyntheticLM(shapes[i], dtype=dtype, device=dev, seed=share_seed if share_seed is not None else seeds[i],
                         logit_scale=logit_scale)
-        can = dev.type == "cuda" and dtype == torch.bfloat16 and shapes[i].head_dim == 128
+        sh = shapes[i]
+        # what asd_decoder_forward's check_shape accepts (csrc/decoder.hip): auto mode falls back to the torch modules for
+        # anything else instead of raising at the first pass; hip_layers=True keeps raising
+        can = (dev.type == "cuda" and dtype == torch.bfloat16 and sh.head_dim == 128 and sh.hidden == sh.heads * sh.head_dim
+               and sh.hidden % 64 == 0 and sh.intermediate % 64 == 0 and sh.hidden <= 8192 and sh.heads % sh.kv_heads == 0)
         if hip_layers or (hip_layers is None and can):
             # pack_weights: the projection matrices re-laid tile-major in place (HipDecoder) where every row count allows it
             packable = pack_weights and all(n % 256 == 0 for n in (shapes[i].hidden, shapes[i].hidden + 2 * shapes[i].kv_heads * shapes[i].head_dim,
@@ -853,7 +942,7 @@ def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: Hie
     tiers: Dict[int, VerifyRole] = {}
     for s in range(1, L):
         ranks_s = placement.ranks_of(s)
-        group = dist.new_group(ranks_s) if len(ranks_s) > 1 else None          # collective: every rank calls it
+        group = dist.new_group(ranks_s, backend=backend) if len(ranks_s) > 1 else None          # collective: every rank calls it
         if rank not in ranks_s:
             continue
         m = make(s)
@@ -868,49 +957,167 @@ def build_rank_roles(rank: int, placement: Placement, shapes: Sequence, cfg: Hie
     return draft, tiers
 
 
-# ---- BASELINE configs[4]: replicated drafts + ONE vocab-sharded target over all ranks -------------------------
+# ---- BASELINE configs[4]: replicated drafts + ONE sharded target over all ranks -------------------------------
+class ShardedTargetRole:
+    """The target tier of BASELINE configs[4] on one rank of N (the reference shards its 72B stage with
+    `tensor_parallel_size: 4`, configs/qwen3_models.yaml:34-51, passed to vLLM at src/serving/real_model_pipeline.py:98-108).
+
+    MI355X placement: 288 GB of HBM hold a whole 72B body (143 GB of bf16 weights) next to the 7B draft, so the BODY is
+    replicated and the WORK is sharded along the batch -- every rank feeds only its own [B/N, K+1] rows through its replica
+    (per-rank KV cache and per-rank model time fall with N; round 3 ran the whole batch through every replica) -- while the
+    lm_head, whose [V, D] matrix is the one operand every row multiplies, stays sharded along the VOCABULARY over all ranks
+    (ShardedHead): each rank streams V/N rows of it for ALL sequences and reduces them to (m2, s, g) triples without forming
+    logits.  Per step the ranks exchange
+
+        all-gather  tok [B/N,K] i32, lp_d [B/N,K] f32, p_0 [B/N] f64                  the drafts                 ~1.2 KB / rank
+        all-gather  final hidden states [B/N, K+1, D] (storage dtype)                  body -> sharded head       2.36 MB / rank (B/N = 16, D = 8192)
+        all-gather  (m2, s, g) [B,K,3] f32                                             inside ShardedHead.score   12 KB at B = 128
+        all-gather  the shard pieces [B, V/N] of ONE target row per sequence           inside ShardedHead.draw_rows
+        all-reduce  MIN of the shortest sequence's length (8 bytes: every rank leaves the loop at the same step)
+
+    and never a [B,K,V] tensor; each rank draws and commits only its own sequences.  Uniforms are drawn for the WHOLE batch from one seeded generator on every rank (as
+    VerifyRole does), so the committed stream does not depend on N (tests/test_hierarchy.py: bit-equal to the one-rank run
+    at world size 2 and 4)."""
+
+    def __init__(self, model, cfg: HierarchyConfig, ops, prompt_local: torch.Tensor, max_new_tokens: int, predictor,
+                 head: "ShardedHead", b0: int, batch_total: int, group=None, feat_local: Optional[torch.Tensor] = None):
+        self.m, self.s, self.cfg, self.ops, self.head, self.group = model, 1, cfg, ops, head, group
+        self.b0, self.Bt = int(b0), int(batch_total)
+        self.st = _SeqState(prompt_local, max_new_tokens, cfg.draft_len)
+        self.b1 = self.b0 + self.st.B
+        dev = prompt_local.device
+        self.gen = _dev_gen(dev, cfg.seed + 7919 * 1)            # VerifyRole's generator of stage 1: the same uniforms
+        self.inv_t = float(np.float32(1.0 / cfg.temperature))
+        self.L = len(cfg.stage_costs)
+        assert self.L == 2, "replicated drafts + one target: two tiers"
+        self.costs = torch.tensor(list(cfg.stage_costs), dtype=torch.float64, device=dev)
+        self.pred = ops.pack_predictor(predictor, dev)
+        self.feat = prompt_features(prompt_local) if feat_local is None else feat_local
+        model.reset()
+        model.alloc_ragged(self.st.B, self.st.kv_slots)
+        model.forward_ragged(prompt_local[:, :self.st.P - 1], torch.zeros((self.st.B,), dtype=torch.int64, device=dev), self.st.P)
+        self.kv_len = torch.full((self.st.B,), self.st.P - 1, dtype=torch.int64, device=dev)
+        self.fed_tokens = 0                                       # model positions THIS rank computed
+        self.fwd_calls = 0
+        self.events: Optional[list] = None
+        self.bytes_exchanged = 0                                  # hidden states + drafts + drawn (the head counts its own)
+        self._r = None
+
+    @torch.no_grad()
+    def body(self, dm_local: DraftMsg) -> torch.Tensor:
+        """The rank's own [B/N, K+1] rows through its replica of the body -> final hidden states [B/N, K+1, D]
+        (row j scores drafted token j, row K is the bonus row).  The tier sees every block, so its cache lags by
+        exactly the last committed token."""
+        st, K, dev = self.st, self.cfg.draft_len, self.st.tokens.device
+        L = st.seq_len.to(torch.int64)
+        kv = self.kv_len
+        pos = kv[:, None] + torch.arange(K + 1, device=dev)
+        committed = st.tokens.gather(1, pos.clamp(max=st.cap - 1)).to(torch.int64)
+        drafted = dm_local.tok.gather(1, (pos - L[:, None]).clamp(0, K - 1)).to(torch.int64)
+        ids = torch.where(pos < L[:, None], committed, drafted)
+        hid = _timed(self, lambda: self.m.forward_ragged(ids, kv, st.window(), return_hidden=True))
+        self.fed_tokens += st.B * (K + 1)
+        self.fwd_calls += 1
+        lag = L - 1 - kv                                          # 0 by construction; kept general
+        sel = lag[:, None] + torch.arange(K + 1, device=dev)
+        return hid.gather(1, sel[:, :, None].expand(-1, -1, hid.shape[-1])).contiguous()
+
+    @torch.no_grad()
+    def score(self, hid_all: torch.Tensor, dm_all: DraftMsg) -> Verdict:
+        """Verdict of the WHOLE batch from the gathered hidden states (vocab-sharded head: every rank computes the same
+        [B] verdict from the all-gathered triples); stop-rule trace for the rank's own slice."""
+        K, dev = self.cfg.draft_len, hid_all.device
+        Bt = self.Bt
+        u = torch.rand((Bt, K), generator=self.gen, device=dev)
+        self._r = torch.rand((Bt,), generator=self.gen, device=dev)
+        lp_t, accept, n_acc, bits = self.head.score(hid_all, dm_all.tok.contiguous(), dm_all.lp_d.contiguous(), u, self.inv_t)
+        sl = slice(self.b0, self.b1)
+        ph = torch.ones((self.st.B, self.L), dtype=torch.float64, device=dev)
+        ph[:, 0] = dm_all.p0[sl]
+        score, k_star, ph = self.ops.predictor_stop(self.pred, lp_t[sl].contiguous(), self.feat, ph, 1, self.costs, self.cfg.lambda_value,
+                                                    self.cfg.risk_adjustment, self.cfg.n_obs, self.cfg.risk_alpha,
+                                                    self.cfg.risk_beta, self.cfg.stats_col)
+        one = torch.ones((Bt,), dtype=torch.int32, device=dev)
+        self._n_acc = n_acc
+        return Verdict(one, one.clone(), n_acc.to(torch.int32), accept=accept, k_star=k_star, score=score, p_hist=ph)
+
+    @torch.no_grad()
+    def draw(self, b_rows_local: torch.Tensor, d_rows: torch.Tensor, d_thr: torch.Tensor) -> torch.Tensor:
+        """The token each of the rank's OWN sequences commits behind its accepted prefix -> [B/N] i32.  The target row of
+        every sequence is assembled from the shard pieces of all ranks (a collective of the group)."""
+        K, dev = self.cfg.draft_len, self.st.tokens.device
+        Bt = self.Bt
+        j_all = self._n_acc.to(torch.int64)
+        t_rows = self.head.draw_rows(torch.arange(Bt, device=dev), j_all)          # [B, V]
+        sl = slice(self.b0, self.b1)
+        t_rows, j = t_rows[sl].contiguous(), j_all[sl]
+        m = self.st.B
+        d_full = torch.zeros_like(t_rows)
+        thr = torch.full((m,), float("-inf"), dtype=torch.float32, device=dev)
+        if b_rows_local.numel():
+            if d_rows.dtype != t_rows.dtype:
+                raise ValueError(f"draft rows are {d_rows.dtype}, the target's logits {t_rows.dtype}: the tiers of a hierarchy "
+                                 "must produce logits of one storage dtype")
+            d_full[b_rows_local] = d_rows
+            thr[b_rows_local] = d_thr
+        all_acc = (j >= K).to(torch.int32)
+        tokd = self.ops.residual_sample(t_rows[:, None, :], d_full[:, None, :], all_acc.contiguous(), self._r[sl].contiguous(),
+                                        t_rows, self.inv_t, d_threshold=thr[:, None].contiguous())
+        return tokd.to(torch.int32)
+
+    def commit(self, dm_local: DraftMsg, final_local: FinalMsg) -> None:
+        cand = self.st.seq_len.to(torch.int64) + final_local.n_acc.to(torch.int64)
+        self.st.commit(self.ops, dm_local.tok, final_local)
+        new_len = self.st.seq_len.to(torch.int64)
+        self.kv_len = torch.minimum(cand, new_len - 1)
+
+
 @torch.no_grad()
-def run_sharded_target_rank(rank: int, world: int, draft: DraftRole, target: VerifyRole, b0: int, b1: int, device,
+def run_sharded_target_rank(rank: int, world: int, draft: DraftRole, target: ShardedTargetRole, device,
                             max_steps: int, group=None) -> HierarchyTrace:
-    """Every rank drafts its own slice [b0, b1) of the batch with its own copy of the draft tier; the target tier's
-    lm_head is split along the vocabulary over ALL ranks (`target.head` is a ShardedHead over `group`, its body is
-    replicated -- tensor-parallel model execution is third-party in the reference), so every rank scores the whole
-    batch.  Per step the ranks exchange
-
-        all-gather  tok [B/N,K] i32, lp_d [B/N,K] f32, p_0 [B/N] f64              (replicated drafts -> everyone)
-        all-gather  (m2, s, g) [B,K,3] f32 per rank                                (inside ShardedHead.score)
-        all-gather  the shard pieces of ONE target row per sequence [B, V/N]       (inside ShardedHead.draw_rows)
-        all-gather  drawn [B/N] i32                                                (each rank draws for its own slice)
-
-    and never a [B,K,V] tensor.  Two tiers (L = 2): the target's verdict is final."""
+    """One rank of BASELINE configs[4]: draft the rank's own slice, run ITS rows through the target body, all-gather the
+    hidden states for the vocab-sharded head, draw and commit the slice (ShardedTargetRole has the exchange list).  Two
+    tiers (L = 2): the target's verdict is final.  The trace's tokens / seq_len are the rank's own sequences; callers that
+    compare streams gather them (tests)."""
     from ..distributed import all_gather_any
-    Bl = b1 - b0
     L = draft.L
-    assert L == 2 and target.s == 1
+    assert L == 2
+    b0, b1 = target.b0, target.b1
     tr = HierarchyTrace(target.st.tokens, target.st.seq_len, tier_counts=[0] * L, tier_calls=[0] * L)
-    K = draft.cfg.draft_len
     while tr.steps < max_steps:
         dm_l = draft.propose()
+        hid_l = target.body(dm_l)
         tok = torch.cat(all_gather_any(dm_l.tok, group), 0)
         lp_d = torch.cat(all_gather_any(dm_l.lp_d, group), 0)
         p0 = torch.cat(all_gather_any(dm_l.p0, group), 0)
+        hid = torch.cat(all_gather_any(hid_l, group), 0)
+        target.bytes_exchanged += (world - 1) * (hid_l.numel() * hid_l.element_size() + dm_l.tok.numel() * 8 + dm_l.p0.numel() * 8)
         dm = DraftMsg(tok, lp_d, p0, torch.zeros((tok.shape[0],), dtype=torch.uint8, device=device))
-        v, _ = target.verify(dm, None)
+        v = target.score(hid, dm)
         v_local = Verdict(v.active[b0:b1], v.stop[b0:b1], v.n_acc[b0:b1])
         bl, d_rows, d_thr = draft.rows_for(v_local)
         tr.rows_shipped += int(bl.numel())
-        drawn = target.draw(bl + b0, d_rows, d_thr, only=(b0, b1))
-        drawn_all = torch.cat(all_gather_any(drawn[b0:b1].contiguous(), group), 0)
-        final = FinalMsg(v.n_acc.contiguous(), drawn_all.contiguous(), torch.ones_like(v.n_acc))
+        drawn_l = target.draw(bl, d_rows, d_thr)
+        final_l = FinalMsg(v_local.n_acc.contiguous(), drawn_l.contiguous(), torch.ones_like(v_local.n_acc))
         before = int(target.st.seq_len.sum().item())
-        draft.commit(dm_l, FinalMsg(final.n_acc[b0:b1].contiguous(), final.drawn[b0:b1].contiguous(),
-                                    final.tier[b0:b1].contiguous()))
-        target.commit(dm, final)
+        draft.commit(dm_l, final_l)
+        target.commit(dm_l, final_l)
         tr.verified_tokens += int(target.st.seq_len.sum().item()) - before
-        tr.tier_counts[1] += int(tok.shape[0])
-        tr.tier_calls[1] += int(tok.shape[0])
+        tr.tier_counts[1] += b1 - b0
+        tr.tier_calls[1] += b1 - b0
         tr.steps += 1
-        if int(target.st.seq_len.min().item()) >= target.st.cap:
+        # every rank must leave the loop at the same step: the shortest sequence of the WHOLE batch decides (8 bytes, all-reduce MIN)
+        shortest = target.st.seq_len.min().to(torch.int64).reshape(1)
+        if world > 1:
+            if shortest.is_cuda and host_staged(group):
+                h = shortest.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MIN, group=group)
+                shortest = h
+            else:
+                dist.all_reduce(shortest, op=dist.ReduceOp.MIN, group=group)
+        if int(shortest.item()) >= target.st.cap:
             break
     tr.fed_tokens = [target.fed_tokens]
+    tr.tier_forwards = [draft.fwd_calls, target.fwd_calls]
+    tr.tier_forward_positions = [draft.fwd_positions, target.fed_tokens]
     return tr

@@ -68,11 +68,20 @@ class HipDecoder:
         self._layers = None
         self._shape = None
         self._scratch: Optional[torch.Tensor] = None
-        self._lin_ws = K.LinearWorkspace(dev)
+        self._lin_ws = K.LinearWorkspace(dev, on_grow=self._drop_graphs)
+
+    def _drop_graphs(self) -> None:
+        """A buffer whose ADDRESS captured hipGraphs hold (KV caches, the decoder scratch, the linear workspace) is about to be
+        replaced: the graphs of the owning SyntheticLM (enable_graphs) would write into memory the allocator may have handed to
+        another tensor.  They are dropped and re-captured on their next use."""
+        g = getattr(self.lm, "_graphs", None)
+        if g:
+            g.clear()
 
     # -- cache
     def alloc(self, batch: int, max_len: int) -> None:
         s = self.lm.shape
+        self._drop_graphs()                        # the caches below replace the ones captured graphs point at
         self.t_max = (int(max_len) + 31) // 32 * 32
         kshape = (batch, s.kv_heads, self.t_max, s.head_dim)
         vshape = (batch, s.kv_heads, s.head_dim, self.t_max)
@@ -93,13 +102,17 @@ class HipDecoder:
         if need == 0:
             raise RuntimeError(f"asd_decoder_scratch_bytes: decoder shape {self.lm.shape} is not supported")
         if self._scratch is None or self._scratch.numel() < need:
+            if self._scratch is not None:
+                self._drop_graphs()
             self._scratch = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         return self._scratch
 
     # -- one pass
     @torch.no_grad()
     def forward(self, ids: torch.Tensor, pos0: torch.Tensor, return_hidden: bool, rows: Optional[torch.Tensor]):
-        """ids [B, T] at positions pos0[b] .. pos0[b] + T - 1 (clamped into the cache); rows: cache rows of the B sequences."""
+        """ids [B, T] at positions pos0[b] .. pos0[b] + T - 1; rows: cache rows of the B sequences.  Positions >= t_max - 1 are
+        clamped into the cache's LAST slot, which is a trash slot for the padding behind a ragged feed: callers size the cache one
+        slot beyond the longest real sequence (hierarchy._SeqState.kv_slots does; alloc rounds up to a multiple of 32 on top)."""
         assert self._layers is not None, "call alloc first"
         lm, s = self.lm, self.lm.shape
         Bn, T = ids.shape

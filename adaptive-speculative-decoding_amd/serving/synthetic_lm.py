@@ -216,7 +216,10 @@ class SyntheticLM(nn.Module):
         self._ragged = None
 
     def alloc_ragged(self, batch: int, max_len: int):
-        """Per-sequence KV cache (N3): one [B, Hkv, max_len, hd] K and V buffer per layer, zero-filled."""
+        """Per-sequence KV cache (N3): one [B, Hkv, max_len, hd] K and V buffer per layer, zero-filled.  Graphs captured by
+        enable_graphs hold the OLD caches' addresses: they are dropped here (and re-captured on their next use)."""
+        if self._graphs:
+            self._graphs = {}
         if self._hip is not None:
             self._hip.alloc(batch, max_len)
             self._ragged = "hip"

@@ -27,9 +27,10 @@ and the max-over-ranks of the times run over gloo, RCCL carries the one exchange
 Before the W warm-up steps the same step runs untimed for ~120 ms (a fresh box needs that to leave its idle clocks; the
 driver's job is 20 steps), and up to 64 steps are captured per graph (a short job is one replay).
 
-roofline: the PLAIN verify kernel's (k_verify<..., FUSED = false>: the batched verify + accept kernel the north star names;
-`roofline.step_kernel` repeats the measurement for the FUSED instantiation the default step launches) ALGORITHMIC bytes (B*K*V*2 + 17*B*K + 4*B, +8*B for
-the ballot word) divided by its mean launch duration.  Duration = HIP events recorded on the launch
+roofline: the ALGORITHMIC bytes (B*K*V*2 + 17*B*K + 4*B, +8*B for the ballot word) of the kernel a TIMED step
+launches -- by default k_verify<..., FUSED = true>, verify + accept + the in-kernel epilogue in one launch -- divided by its mean
+launch duration; `roofline.plain_kernel` repeats the measurement for the plain streaming kernel (FUSED = false: what
+--two-launch runs first), which is NOT what `value` was computed from.  Duration = HIP events recorded on the launch
 stream around a back-to-back run of the verify kernel alone over the same rotating buffers, taken
 right after the timed region in the same process (it includes the inter-kernel gap, so it is a
 slight over-estimate; it agrees with rocprofv3's kernel average within ~1 %, see profiles/).
@@ -161,12 +162,14 @@ def cpu_baseline(np, torch, buf, B, K, V, weights, feat, budget_s=12.0):
                                      f"with torch CPU f32, {rows}-row sample")
 
 
-def load_traffic():
-    """HBM bytes per verify launch from the last committed PMC pass (profiles/*traffic.json), or None."""
+def load_traffic(fused=False):
+    """HBM bytes per verify launch from the last committed PMC pass (profiles/rNN_traffic.json: the plain kernel;
+    rNN_traffic_fused.json: the FUSED instantiation), or None."""
     pdir = os.path.join(ROOT, "profiles")
     try:
         import re
-        cands = sorted(f for f in os.listdir(pdir) if re.fullmatch(r"r\d+_traffic\.json", f))   # the PLAIN kernel's record of the latest round
+        pat = r"r\d+_traffic_fused\.json" if fused else r"r\d+_traffic\.json"
+        cands = sorted(f for f in os.listdir(pdir) if re.fullmatch(pat, f))   # the latest round's record
     except OSError:
         return None, None
     if not cands:
@@ -219,9 +222,11 @@ def _timed_ops(torch):
 
 
 def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, warmup, steps, heads=("logits", "fused"),
-                   logit_scale=0.6, target_stop_rate=0.66, lam=None, seed=5):
+                   logit_scale=0.6, target_stop_rate=0.66, lam=None, seed=5, group=None):
     """Run `warmup` + `steps` steps of the three-tier stop-or-escalate loop under Placement.for_world(world) and
-    return the record (rank 0) -- timed like the headline: barrier + synchronize on both sides, max over ranks."""
+    return the record (rank 0) -- timed like the headline: barrier + synchronize on both sides, max over ranks.
+    group: the DATA-path process group (RCCL: the small point-to-point messages and the vocab-sharded tier's all-gathers move
+    device tensors over xGMI); barriers and the reductions of the timings use the default group."""
     from asd_amd.minimal_adaptive_decoder import MinimalQualityPredictor
     from asd_amd.serving import hierarchy as H
     from asd_amd.serving.synthetic_lm import QWEN25_SHAPES, tiny
@@ -244,9 +249,10 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
     # model execution: the HIP decoder stack (asd_decoder_forward: 9 launches per layer) unless ASD_LOOP_TORCH_MODULES=1 asks
     # for the torch modules of rounds 1-3 (~50 launches per layer) as the comparison
     hip_layers = False if os.environ.get("ASD_LOOP_TORCH_MODULES", "0") == "1" else None
+    data_backend = dist.get_backend(group) if (world > 1 and group is not None) else None
     draft, tiers = H.build_rank_roles(rank, pl, shp, cfg, prompt, new_tokens, pred, ops=ops, heads=heads,
                                       logit_scale=logit_scale, seeds=(1, 2, 3), hip_layers=hip_layers,
-                                      pack_weights=os.environ.get("ASD_LOOP_PACK_WEIGHTS", "1") == "1")
+                                      pack_weights=os.environ.get("ASD_LOOP_PACK_WEIGHTS", "1") == "1", backend=data_backend)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     L = len(shp)
@@ -265,7 +271,7 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
         if world == 1:
             return H.generate_hierarchical(draft, [tiers[s] for s in range(1, L)], max_steps=n, controller=ctrl["c"])
         return H.run_hierarchical_rank(rank, pl, draft, tiers, B, K, L, V, torch.bfloat16, prompt_len + new_tokens, device,
-                                       max_steps=n, controller=ctrl["c"])
+                                       max_steps=n, controller=ctrl["c"], group=group)
 
     def barrier():
         if world > 1:
@@ -282,7 +288,7 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
                 tr0 = H.generate_hierarchical(draft, [tiers[s] for s in range(1, L)], max_steps=1, keep_inputs=True)
             else:
                 tr0 = H.run_hierarchical_rank(rank, pl, draft, tiers, B, K, L, V, torch.bfloat16, prompt_len + new_tokens,
-                                              device, max_steps=1, keep_inputs=True)
+                                              device, max_steps=1, keep_inputs=True, group=group)
         lam_t = torch.zeros(2, dtype=torch.float64, device=red)
         if 1 in tiers and rank == pl.leader(1):
             v1 = tr0.records[0]["tiers"][1][0]
@@ -371,6 +377,8 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
         "lambda": cfg.lambda_value, "lambda_calibration": calib, "stage_costs": list(cfg.stage_costs),
         "tier_counts": tr.tier_counts, "stop_rate": tr.stop_rate, "tier_calls": tr.tier_calls,
         "fed_tokens": tr.fed_tokens, "draft_rows_shipped": tr.rows_shipped, "bytes_sent_from_draft_rank": tr.bytes_sent,
+        "bytes_sent": tr.bytes_sent, "messages_sent": getattr(tr, "messages_sent", {}),
+        "rccl_ranks": (dist.get_world_size(group) if world > 1 else 1), "backend": (dist.get_backend(group) if world > 1 else None),
         "hot_path_ms_per_step_on_draft_rank": hot_ms / max(1, tr.steps),
         "hot_path_calls": {k: {"ms": v[0], "calls": v[1]} for k, v in hot.items()},
         "hot_path_share": hot_ms / (1e3 * elapsed), "build_s": build_s,
@@ -384,10 +392,13 @@ def hierarchy_loop(torch, dist, device, rank, world, shapes, B, K, prompt_len, w
     return rec
 
 
-def sharded_target_loop(torch, dist, device, rank, world, shapes, B_local, K, prompt_len, warmup, steps, logit_scale=0.6, seed=5):
-    """BASELINE configs[4]: every rank drafts its own B_local sequences (replicated draft tier), the target tier's
-    lm_head is vocabulary-sharded over ALL ranks (asd_lm_head_partial + [B,K,3] all-gather; the body is replicated:
-    tensor-parallel model execution is third-party).  Weak scaling: the batch grows with the ranks."""
+def sharded_target_loop(torch, dist, device, rank, world, shapes, B_local, K, prompt_len, warmup, steps, logit_scale=0.6, seed=5,
+                        group=None):
+    """BASELINE configs[4]: every rank drafts its own B_local sequences (replicated draft tier) and runs ITS rows through its
+    replica of the target body (288 GB hold the 143 GB of a 72B body next to the draft: the WORK is sharded along the batch, the
+    per-rank model pass does not grow with N); the target's lm_head is vocabulary-sharded over ALL ranks
+    (hierarchy.ShardedTargetRole: all-gather of the final hidden states [B/N, K+1, D], asd_lm_head_partial, [B,K,3] all-gather).
+    Weak scaling: the batch grows with the ranks.  group: the data-path group (RCCL); control reductions use the default group."""
     from asd_amd.minimal_adaptive_decoder import MinimalQualityPredictor
     from asd_amd.serving import hierarchy as H
     from asd_amd.serving.synthetic_lm import QWEN25_SHAPES, SyntheticLM, tiny
@@ -412,10 +423,10 @@ def sharded_target_loop(torch, dist, device, rank, world, shapes, B_local, K, pr
     tm = SyntheticLM(t_shape, dtype=torch.bfloat16, device=device, seed=3, logit_scale=logit_scale)
     if os.environ.get("ASD_LOOP_TORCH_MODULES", "0") != "1" and t_shape.head_dim == 128:
         tm.enable_hip_layers()
-    head = H.ShardedHead(tm, ops, V, group=None)
+    head = H.ShardedHead(tm, ops, V, group=group)
     tm.lm_head.weight = torch.nn.Parameter(tm.lm_head.weight[head.v0:head.v1].clone(), requires_grad=False)
     torch.cuda.empty_cache()
-    target = H.VerifyRole(tm, 1, cfg, ops, prompt, new_tokens, pred, head=head)
+    target = H.ShardedTargetRole(tm, cfg, ops, prompt[b0:b1].contiguous(), new_tokens, pred, head, b0, Bt, group=group)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     red = torch.device("cpu") if dist.get_backend() == "gloo" else device
@@ -423,34 +434,74 @@ def sharded_target_loop(torch, dist, device, rank, world, shapes, B_local, K, pr
     def barrier():
         dist.all_reduce(torch.zeros(1, device=red))
 
-    if warmup:
-        H.run_sharded_target_rank(rank, world, draft, target, b0, b1, device, max_steps=warmup)
+    if warmup:                                       # also builds the data group's communicator before the timed steps
+        H.run_sharded_target_rank(rank, world, draft, target, device, max_steps=warmup, group=group)
     ops.totals_ms()
     head.bytes_exchanged = 0
+    target.bytes_exchanged = 0
+    target.fed_tokens = 0
+    target.fwd_calls = draft.fwd_calls = draft.fwd_positions = 0
+    draft.events, target.events = [], []
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tr = H.run_sharded_target_rank(rank, world, draft, target, b0, b1, device, max_steps=steps)
+    tr = H.run_sharded_target_rank(rank, world, draft, target, device, max_steps=steps, group=group)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     hot = ops.totals_ms()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    t = torch.tensor([elapsed, 0.0], dtype=torch.float64, device=red)
+    dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+    elapsed = float(t[0].item())
+    tk = torch.tensor([float(tr.verified_tokens)], dtype=torch.float64, device=red)
+    dist.all_reduce(tk, op=dist.ReduceOp.SUM)        # every rank commits its own sequences: the job's tokens are the sum
+    verified = int(tk.item())
+    model_ms = {"tier0_draft": {"ms": sum(a.elapsed_time(b_) for a, b_ in draft.events), "passes": len(draft.events)},
+                "tier1_target": {"ms": sum(a.elapsed_time(b_) for a, b_ in target.events), "passes": len(target.events)}}
+    draft.events = target.events = None
     if rank != 0:
         return None
     hot_ms = sum(v[0] for v in hot.values())
+
+    def stream_bytes(model):
+        total = sum(p_.numel() * p_.element_size() for p_ in model.parameters())
+        return total - model.embed.weight.numel() * model.embed.weight.element_size()
+    # per-RANK roofline of the step (weak scaling: the same on every rank): every model pass streams its weights once; the
+    # target's lm_head shard is streamed once for the gathered [B, K] rows
+    ctx = prompt_len + (warmup + steps // 2) * (K + 1) * 0.6
+    per = {}
+    rank_bytes = 0.0
+    for name, role, passes, positions, seqs in (("tier0_draft", draft, tr.tier_forwards[0], tr.tier_forward_positions[0], tr.tier_forward_positions[0]),
+                                                ("tier1_target", target, tr.tier_forwards[1], tr.tier_forward_positions[1],
+                                                 tr.tier_forward_positions[1] / (K + 1))):
+        shp_ = role.m.shape
+        kv = 2.0 * shp_.layers * shp_.kv_heads * shp_.head_dim * ctx * 2 * seqs
+        b_ = passes * stream_bytes(role.m) + kv + (2.0 * positions * V * 2 if role is draft else 0.0)
+        rank_bytes += b_
+        per[name] = {"weights_GB": stream_bytes(role.m) / 1e9, "passes": passes, "positions": positions, "bytes_GB": b_ / 1e9,
+                     "floor_ms_at_8TBs": 1e3 * b_ / 8e12, "model_ms": model_ms[name]["ms"]}
+    roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": rank_bytes / elapsed / 1e9,
+            "frac": rank_bytes / elapsed / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": rank_bytes / max(1, tr.steps),
+            "floor_ms_per_step_at_8TBs": 1e3 * rank_bytes / max(1, tr.steps) / 8e12, "per_tier": per,
+            "what": "PER RANK (rank 0): bytes of every model pass of this rank (weights once per pass + K/V attended + the draft's "
+                    "logits written and re-read; the target's logits never reach HBM) / step time"}
     return {
-        "tiers": [d_shape.name, t_shape.name], "placement": f"replicated {d_shape.name} drafts on every rank + {t_shape.name} "
-        f"target with a vocab-sharded lm_head over {world} rank(s)", "batch_total": Bt, "batch_per_rank": B_local,
-        "draft_len": K, "prompt_len": prompt_len, "steps": tr.steps, "warmup": warmup, "verified_tokens": tr.verified_tokens,
-        "seconds": elapsed, "verified_tokens_per_s": tr.verified_tokens / elapsed, "ms_per_step": 1e3 * elapsed / max(1, tr.steps),
-        "tokens_per_sequence_step": tr.verified_tokens / max(1, tr.steps * Bt),
-        "bytes_exchanged_per_step_rank0": head.bytes_exchanged / max(1, tr.steps),
+        "tiers": [d_shape.name, t_shape.name],
+        "placement": f"replicated {d_shape.name} drafts on every rank; {t_shape.name} target: body replicated, its WORK sharded along "
+                     f"the batch ({B_local} sequences per rank), lm_head vocab-sharded over {world} rank(s)",
+        "rccl_ranks": dist.get_world_size(group), "backend": dist.get_backend(group),
+        "batch_total": Bt, "batch_per_rank": B_local,
+        "draft_len": K, "prompt_len": prompt_len, "steps": tr.steps, "warmup": warmup, "verified_tokens": verified,
+        "seconds": elapsed, "verified_tokens_per_s": verified / elapsed, "ms_per_step": 1e3 * elapsed / max(1, tr.steps),
+        "tokens_per_sequence_step": verified / max(1, tr.steps * Bt),
+        "fed_tokens_per_rank_per_step": tr.fed_tokens[0] / max(1, tr.steps),
+        "bytes_sent": {"hidden_states+drafts": target.bytes_exchanged, "triples+row_pieces": head.bytes_exchanged},
+        "bytes_exchanged_per_step_rank0": (head.bytes_exchanged + target.bytes_exchanged) / max(1, tr.steps),
         "hot_path_ms_per_step": hot_ms / max(1, tr.steps), "hot_path_share": hot_ms / (1e3 * elapsed),
         "hot_path_calls": {k: {"ms": v[0], "calls": v[1]} for k, v in hot.items()}, "build_s": build_s,
-        "models": f"synthetic random-weight Qwen2.5 shapes, logit_scale {logit_scale}; target body replicated on every rank",
+        "roofline": roof, "model_ms": model_ms,
+        "model_execution": {"tier0_draft": draft.m.execution, "tier1_target": target.m.execution},
+        "models": f"synthetic random-weight Qwen2.5 shapes, logit_scale {logit_scale}",
     }
 
 
@@ -796,15 +847,32 @@ def _spawn_ranks(n, argv, timeout_s):
             result = ln
         else:
             print(ln, file=sys.stderr)
+    if result is not None:                    # the headline is relayed even when the job failed afterwards (a hang in the data-path
+        sys.stdout.write(result + "\n")       # phase: rank 0 printed the line with the error recorded, then every rank left non-zero)
+        sys.stdout.flush()
     if failed:
         print(f"[bench] {failed}", file=sys.stderr)
         return 1
     if result is None:
         print("[bench] rank 0 printed no result line", file=sys.stderr)
         return 1
-    sys.stdout.write(result + "\n")
-    sys.stdout.flush()
     return 0
+
+
+# Which bounded `loop` sub-record the DEFAULT multi-GPU line carries (BASELINE configs[3] / [4]; the reference's placement is
+# configs/qwen3_models.yaml:5-53: 7B [0], 32B [1], 72B tensor-parallel over the rest).
+LOOP_KEYS = ("kind", "placement", "rccl_ranks", "backend", "verified_tokens_per_s", "ms_per_step", "steps", "roofline", "bytes_sent")
+
+
+def multi_gpu_plan(world):
+    """N = 2 ... 7: the three-tier stop-or-escalate loop with the tiers placed over the ranks (N = 2: {7B + 32B | 72B};
+    N >= 4: 7B | 32B | 72B vocab-sharded over up to four ranks), small messages point-to-point.  N >= 8: replicated 7B drafts +
+    the 72B target sharded over ALL ranks (work along the batch, lm_head along the vocabulary), batch 16 per rank = 128 at N = 8."""
+    if world >= 8:
+        return {"kind": "sharded-target", "placement": f"replicated 7b drafts + 72b target sharded over {world} ranks, batch {16 * world}",
+                "batch_per_rank": 16}
+    tiers = {2: [[0], [1]], 3: [[1], [2]]}.get(world, [[1], list(range(2, min(world, 6)))])
+    return {"kind": "tiers", "placement": {"draft": 0, "tiers": tiers, "ranks": world}, "batch": 32}
 
 
 def main_dry(args):
@@ -831,15 +899,49 @@ def main_dry(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
+    out = None
     if rank == 0:
         B, K, V, desc = WORKLOADS[args.workload]
-        _emit({"metric": "verified_tokens_per_s", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        out = {"metric": "verified_tokens_per_s", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "bf16", "data": "none (dry run of the launcher: no kernel ran)",
                "dry_run": True, "config": {"workload": f"{args.workload}: {desc}", "parallelism": f"{world} rank(s), gloo, no GPU",
-                                           "spawned_by_bench": os.environ.get("ASD_BENCH_SPAWNED") == "1"}})
+                                           "spawned_by_bench": os.environ.get("ASD_BENCH_SPAWNED") == "1"}}
+    if world > 1 and not args.no_loop:
+        # the data-path phase of the default multi-GPU line (sharded_verify + the bounded loop), as PLUMBING: the same watchdog,
+        # the same sub-record keys (values null), one collective standing in for the exchanges
+        plan = multi_gpu_plan(world)
+        state = {"out": out, "phase": "loop"}
+        wd = _start_watchdog(args.multi_gpu_timeout, rank, state)
+        if args.dry_stall_rank == rank:
+            time.sleep(3600)                  # test hook: a rank that hangs in the data path (the others block in the collective)
+        dist.all_reduce(torch.zeros(1))
+        wd.cancel()
+        if out is not None:
+            out["sharded_verify"] = {"ranks": world, "backend": "none (dry run)"}
+            out["loop"] = dict({k: None for k in LOOP_KEYS}, kind=plan["kind"], placement=plan["placement"], rccl_ranks=world,
+                               backend="none (dry run)")
+    if rank == 0:
+        _emit(out)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _start_watchdog(seconds, rank, state):
+    """The data-path phase of a multi-GPU run is bounded: if a collective hangs, rank 0 prints the headline -- measured before,
+    over gloo -- with the error recorded in the sub-record that was running, and EVERY rank leaves with a non-zero code: a
+    process that touched the GPU and then hung is a failed run whatever it printed (and must not linger on the device)."""
+    import threading
+
+    def bail():
+        if rank == 0 and state.get("out") is not None:
+            state["out"][state.get("phase", "loop")] = {"error": f"timed out after {seconds:.0f} s"}
+            _emit(state["out"])
+        os._exit(3)
+    t = threading.Timer(seconds, bail)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
@@ -889,6 +991,10 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only: no kernel, no GPU, `value` null (CPU test of --gpus N)")
     ap.add_argument("--dry-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-stall-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--multi-gpu-timeout", type=float, default=900.0,
+                    help="N > 1: seconds the data-path phase (sharded_verify + the bounded loop sub-record) may take before the "
+                         "headline is printed with the error recorded and every rank exits non-zero")
     ap.add_argument("--launch-timeout", type=float, default=3000.0,
                     help="--gpus N started without torch.distributed.run: seconds after which the spawned ranks are ended")
     args = ap.parse_args()
@@ -1221,24 +1327,15 @@ def main():
             loop_rec = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
 
-    pending_watchdog = None
-    state = {"out": None}
-    if distributed and not args.no_loop:
-        # N > 1: the exchange step of a vocab-sharded target over THIS job's ranks (RCCL all-gather + the HIP kernels).
-        # Bounded by a watchdog: if the collective hangs, every rank leaves and rank 0 still prints the headline.
-        import threading
-
-        def bail():
-            if rank == 0 and state["out"] is not None:
-                state["out"]["sharded_verify"] = {"error": "timed out after 120 s"}
-                _emit(state["out"])
-            os._exit(0)
-        pending_watchdog = threading.Timer(120.0, bail)
-        pending_watchdog.daemon = True
-
     if rank == 0:
+        # roofline: the kernel the TIMED step launches (the FUSED instantiation unless --two-launch / --verify-only); the plain
+        # streaming kernel's figures sit beside it as `plain_kernel`
+        step_is_fused = bool(fused_runs)
+        plain_ms, plain_min_ms, plain_runs = kern_mean_ms, kern_min_ms, runs
+        if step_is_fused:
+            kern_mean_ms, kern_min_ms, runs = sum(fused_runs) / len(fused_runs), min(fused_runs), fused_runs
         achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
-        traffic, traffic_src = load_traffic()
+        traffic, traffic_src = load_traffic(fused=step_is_fused)
         out = {
             "metric": "verified_tokens_per_s",
             "value": tokens / elapsed,
@@ -1268,21 +1365,22 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
                          "traffic_source": traffic_src,
-                         "kernel": "asd::k_verify (verify_accept.hip)", "algorithmic_bytes": bytes_per_launch,
+                         "kernel": ("asd::k_verify<..., FUSED = true> (verify_accept.hip): verify + accept + the in-kernel statistics / predictor / "
+                                    "Bayes / DP epilogue -- the ONE kernel a timed step launches") if step_is_fused else
+                                   "asd::k_verify<..., FUSED = false> (verify_accept.hip): the step's dominant kernel",
+                         "algorithmic_bytes": bytes_per_launch,
                          "kernel_ms_mean": kern_mean_ms, "kernel_ms_best_run": kern_min_ms, "kernel_ms_runs": runs,
-                         "timing": f"HIP events on the launch stream around 5 runs of {reps} back-to-back verify launches "
+                         "timing": f"HIP events on the launch stream around 5 runs of {reps} back-to-back launches of that kernel "
                                    "(rotating buffers) right after the timed region; includes inter-kernel gaps",
                          "note": "event PAIRS around single launches add 5-15 us each on this stack (measured in round 1) and are not used"},
         }
-        if fused_runs:
-            fm = sum(fused_runs) / len(fused_runs)
-            out["roofline"]["step_kernel"] = {
-                "kernel": "asd::k_verify<..., FUSED> (verify + in-kernel predictor / Bayes / DP epilogue; the default step's one launch)",
-                "kernel_ms_mean": fm, "kernel_ms_runs": fused_runs, "achieved": bytes_per_launch / (fm * 1e-3) / 1e9,
-                "frac": bytes_per_launch / (fm * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "same algorithmic bytes; the duration includes the epilogue the two-launch step runs as a second kernel "
-                        "(asd_predictor_stop, ~4 us + launch gap).  `frac` above is the streaming kernel named by the north star "
-                        "(plain instantiation, what --two-launch runs)"}
+        if step_is_fused:
+            out["roofline"]["plain_kernel"] = {
+                "kernel": "asd::k_verify<..., FUSED = false>: the streaming verify + accept kernel alone (what --two-launch runs as its first launch)",
+                "kernel_ms_mean": plain_ms, "kernel_ms_best_run": plain_min_ms, "kernel_ms_runs": plain_runs,
+                "achieved": bytes_per_launch / (plain_ms * 1e-3) / 1e9,
+                "frac": bytes_per_launch / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "same algorithmic bytes, same measurement; NOT the kernel `value` was computed from"}
         if others:
             out["roofline"]["other_workloads_kernel_only"] = others
         if loop_rec is not None:
@@ -1291,18 +1389,40 @@ def main():
             out["cpu_baseline"] = cpu_baseline(np, torch, cpu_buf, B, K, V, weights, feat_np, args.cpu_budget_s)
     else:
         out = None
-    if pending_watchdog is not None:
-        state["out"] = out
-        pending_watchdog.start()
+    if distributed and not args.no_loop:
+        # N > 1, default arguments: the data path of the multi-GPU configurations, bounded by ONE watchdog (a hang prints the
+        # headline with the error recorded and exits non-zero):
+        #   sharded_verify  the exchange step of a vocab-sharded 72B-shape head over this job's ranks (kernels + one all-gather)
+        #   loop            BASELINE configs[3] at N = 2 ... 7 (tiers placed over the ranks), configs[4] at N >= 8 (replicated
+        #                   drafts + sharded target, batch 16 per rank), real shapes, a few steps
+        state = {"out": out, "phase": "sharded_verify"}
+        wd = _start_watchdog(args.multi_gpu_timeout, rank, state)
+        bufs = cpu_buf = None
+        torch.cuda.empty_cache()
         try:
-            bufs = cpu_buf = None
-            torch.cuda.empty_cache()
             sharded_rec = sharded_verify_step(torch, dist, device, rank, world, B, K, V, group=data_group)
         except Exception as e:  # noqa: BLE001
             sharded_rec = {"error": f"{type(e).__name__}: {e}"}
-        pending_watchdog.cancel()
         if out is not None:
             out["sharded_verify"] = sharded_rec
+        state["phase"] = "loop"
+        plan = multi_gpu_plan(world)
+        torch.cuda.empty_cache()
+        try:
+            if plan["kind"] == "sharded-target":
+                shapes_ = args.tier_shapes.split(",")
+                rec = sharded_target_loop(torch, dist, device, rank, world, [shapes_[0], shapes_[-1]], plan["batch_per_rank"], K, 32, 2,
+                                          args.loop_steps, group=data_group)
+            else:
+                rec = hierarchy_loop(torch, dist, device, rank, world, args.tier_shapes.split(","), args.loop_batch, K, 32, 2,
+                                     args.loop_steps, lam=args.lam, target_stop_rate=args.stop_rate, group=data_group)
+            if rec is not None:
+                rec["kind"] = plan["kind"]
+        except Exception as e:  # noqa: BLE001  (the headline must not depend on the context record)
+            rec = {"kind": plan["kind"], "error": f"{type(e).__name__}: {e}"}
+        wd.cancel()
+        if out is not None:
+            out["loop"] = rec
     if rank == 0:
         _emit(out)
     if distributed:

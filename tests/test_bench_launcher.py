@@ -66,3 +66,34 @@ def test_two_replica_ranks_on_one_gpu_from_a_plain_process():
     d = _one_line(r.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["frac"] < 1.0
+
+
+@pytest.mark.parametrize("n,kind", [(2, "tiers"), (4, "tiers"), (8, "sharded-target")])
+def test_default_multi_gpu_line_carries_the_loop_sub_record_of_its_configuration(n, kind):
+    """the BARE command (`bench.py --gpus N`, what the driver runs) must exercise BASELINE configs[3] at
+    N = 2 / 4 (tiers placed over the ranks, the reference's configs/qwen3_models.yaml:5-53) and configs[4] at N = 8 (replicated
+    drafts + sharded target).  The dry run walks the same branch and prints the sub-record's keys with null values."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--dry-run", "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    loop = d["loop"]
+    assert loop["kind"] == kind and loop["rccl_ranks"] == n
+    for key in ("kind", "placement", "rccl_ranks", "backend", "verified_tokens_per_s", "ms_per_step", "steps", "roofline", "bytes_sent"):
+        assert key in loop, key
+    if kind == "tiers":
+        want = {2: [[0], [1]], 4: [[1], [2, 3]]}[n]
+        assert loop["placement"]["tiers"] == want and loop["placement"]["draft"] == 0
+    else:
+        assert "sharded over 8 ranks" in loop["placement"] and "batch 128" in loop["placement"]
+    assert d["sharded_verify"]["ranks"] == n
+
+
+def test_a_rank_that_hangs_in_the_data_path_fails_the_job_but_the_headline_is_printed():
+    """A collective that never completes: the watchdog prints the headline with the error recorded in the sub-record that was
+    running and EVERY rank exits non-zero (round 3 left with exit code 0)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--dry-stall-rank", "1", "--multi-gpu-timeout", "4",
+                        "--launch-timeout", "90"], capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode != 0
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 2 and "timed out" in d["loop"]["error"]

@@ -209,7 +209,8 @@ def _gpu_rank_worker(rank, world, port, mode, ret):
             assert torch.equal(got.tokens, want.tokens) and got.tier_counts == want.tier_counts
             assert 0 < got.tier_counts[1] < sum(got.tier_counts)
             if rank == pl.draft:
-                assert got.bytes_sent.get("rows", 0) <= got.rows_shipped * (V * 2 + 4) * len(pl.ranks_of(2))
+                # (a message is ONE buffer, each tensor segment padded to 8 bytes: + <= 16 bytes per `rows` message)
+                assert got.bytes_sent.get("rows", 0) <= got.rows_shipped * (V * 2 + 4) * len(pl.ranks_of(2)) + 16 * got.messages_sent.get("rows", 0)
         else:                                   # replicated drafts + vocab-sharded target (BASELINE configs[4])
             solos = [dist.new_group([r]) for r in range(world)]
             Bt = 8
@@ -224,13 +225,14 @@ def _gpu_rank_worker(rank, world, port, mode, ret):
                 m = _model(0.03, 9, dt, dev)
                 head = H.ShardedHead(m, ops, V, group=group)
                 m.lm_head.weight = torch.nn.Parameter(m.lm_head.weight[head.v0:head.v1].clone(), requires_grad=False)
-                t = H.VerifyRole(m, 1, cfg, ops, prompt, NEW, pred, head=head)
-                return H.run_sharded_target_rank(r, n, d, t, b0, b1, dev, max_steps=NEW + 4, group=group)
-            want = run(solos[rank], 1, 0)
-            got = run(None, world, rank)
+                t = H.ShardedTargetRole(m, cfg, ops, prompt[b0:b1].contiguous(), NEW, pred, head, b0, Bt, group=group)
+                return H.run_sharded_target_rank(r, n, d, t, dev, max_steps=NEW + 4, group=group), t, (b0, b1)
+            want, _, _ = run(solos[rank], 1, 0)
+            got, t, (b0, b1) = run(None, world, rank)
             # the shard merge order differs from the one-shard run in the last bits of lp_t only: same decisions, same stream
-            assert torch.equal(got.tokens, want.tokens), "sharded-target stream differs from the one-rank run"
+            assert torch.equal(got.tokens, want.tokens[b0:b1]), "sharded-target stream differs from the one-rank run"
             assert (got.seq_len == P + NEW).all()
+            assert t.fed_tokens == got.steps * (b1 - b0) * (K + 1)          # the body ran over this rank's rows only
         torch.cuda.synchronize()
         ret[rank] = "ok"
     finally:

@@ -194,12 +194,24 @@ def _rank_worker(rank, world, port, ret):
         if rank == pl.draft:
             # bytes that crossed a link from the draft rank: the fixed small messages + ONE row per stop-with-rejection
             small = tr.steps * (B * K * 8 + B * 9) * world + tr.steps * 3 * B * 4 * world
+            msgs = tr.messages_sent
+            pad = 8 * 4 * sum(msgs.values())          # a message is one buffer, every tensor segment padded to 8 bytes
             rows = tr.bytes_sent.get("rows", 0)
-            assert rows <= tr.rows_shipped * (V * 4 + 4) * max(1, len(pl.ranks_of(2)))
-            assert rows <= sum(tr.tier_counts) * (V * 4 + 4) * max(1, len(pl.ranks_of(2)))
+            assert rows <= tr.rows_shipped * (V * 4 + 4) * max(1, len(pl.ranks_of(2))) + 16 * msgs.get("rows", 0)
+            assert rows <= sum(tr.tier_counts) * (V * 4 + 4) * max(1, len(pl.ranks_of(2))) + 16 * msgs.get("rows", 0)
             other = sum(v for k, v in tr.bytes_sent.items() if k != "rows")
-            assert other <= small, (other, small)
+            assert other <= small + pad, (other, small, pad)
             assert tr.bytes_sent.get("draft", 0) > 0
+            # ONE backend call per (message, destination) and step: the draft rank sends `draft` to every verify rank, `rows` to
+            # the ranks of a tier that ran, `final` to everyone else
+            verify_ranks = sorted({r for t in pl.tiers for r in t} - {pl.draft})
+            assert msgs["draft"] == tr.steps * len(verify_ranks)
+            assert msgs["final"] == tr.steps * len(sorted(({pl.draft} | {r for t in pl.tiers for r in t}) - {pl.draft}))
+            assert msgs.get("rows", 0) <= tr.steps * sum(len([r for r in pl.ranks_of(s_) if r != pl.draft]) for s_ in (1, 2))
+        elif tr.messages_sent:
+            for name, n in tr.messages_sent.items():  # a verify leader: verdict / drawn to the draft rank, escalate to the next tier's ranks
+                dests = {"verdict": 1, "drawn": 1, "escalate": len(pl.ranks_of(2))}.get(name, world)
+                assert n <= tr.steps * dests, (name, n)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -240,18 +252,23 @@ def _sharded_worker(rank, world, port, ret):
             m = _model(0.03, 9)
             head = H.ShardedHead(m, ops, V, group=group)
             m.lm_head.weight = torch.nn.Parameter(m.lm_head.weight[head.v0:head.v1].clone(), requires_grad=False)
-            t = H.VerifyRole(m, 1, cfg, ops, prompt, NEW, pred, head=head)
-            return H.run_sharded_target_rank(r, n, d, t, b0, b1, "cpu", max_steps=NEW + 4, group=group), head
+            t = H.ShardedTargetRole(m, cfg, ops, prompt[b0:b1], NEW, pred, head, b0, Bt, group=group)
+            return H.run_sharded_target_rank(r, n, d, t, "cpu", max_steps=NEW + 4, group=group), head, t, (b0, b1)
 
-        want, _ = run(solos[rank], 1, 0)                                # the whole batch on one rank
-        got, head = run(None, world, rank)                              # replicated drafts, target sharded over all ranks
-        assert torch.equal(got.tokens, want.tokens) and torch.equal(got.seq_len, want.seq_len)
+        want, _, t1, _ = run(solos[rank], 1, 0)                         # the whole batch on one rank
+        got, head, t, (b0, b1) = run(None, world, rank)                 # replicated drafts; the target's WORK cut over the ranks
+        # the rank commits its own sequences: bit for bit the one-rank run's rows
+        assert torch.equal(got.tokens, want.tokens[b0:b1]) and torch.equal(got.seq_len, want.seq_len[b0:b1])
         assert (got.seq_len == P + NEW).all() and got.steps == want.steps
-        accepted = got.verified_tokens - got.steps * Bt
+        accepted = got.verified_tokens - got.steps * (b1 - b0)
         assert accepted > 0                                             # some drafted tokens were accepted
-        # exchange volume per rank: triples + one row piece per sequence and step, never a [B,K,V] tensor
-        per_step = head.bytes_exchanged / got.steps
-        assert per_step <= (Bt * K * 12 + Bt * (V // world + 1) * 4) * (world - 1) + 64
+        # the body ran over THIS rank's rows only: B/N * (K+1) positions per step (round 3: the whole batch on every rank)
+        assert t.fed_tokens == got.steps * (b1 - b0) * (K + 1) and t1.fed_tokens == want.steps * Bt * (K + 1)
+        assert t.st.B == b1 - b0                                        # ... and so did its KV cache
+        # exchange volume per rank: hidden states of its rows + triples + one row piece per sequence and step, never [B,K,V]
+        D_ = t.m.shape.hidden
+        per_step = (head.bytes_exchanged + t.bytes_exchanged) / got.steps
+        assert per_step <= ((b1 - b0) * (K + 1) * D_ * 4 + (b1 - b0) * (K * 8 + 8) + Bt * K * 12 + Bt * (V // world + 1) * 4) * (world - 1) + 64
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -259,8 +276,9 @@ def _sharded_worker(rank, world, port, ret):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_replicated_drafts_with_a_vocab_sharded_target(world):
-    """BASELINE configs[4] in miniature: every rank drafts its slice, the target's lm_head is split over all ranks;
-    the committed stream equals the one-rank run's."""
+    """BASELINE configs[4] in miniature: every rank drafts its slice and runs ITS rows through the target body, the
+    target's lm_head is split over all ranks (hidden states all-gathered); the committed stream equals the one-rank run's
+    and the per-rank body work is B/N * (K+1) positions per step."""
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
