@@ -43,13 +43,10 @@ SIGNATURES = {
     "asd_verify_accept_fused_ex": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                         _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d, _i, _i, _i, _vp,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "asd_debug_verify_withhold": (_i, [_i]),
     "asd_residual_sample_workspace_bytes": (_sz, [_i, _i, _i]),
-    "asd_debug_residual_groups": (_i, [_i]),
     "asd_residual_sample": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "asd_residual_sample_ex": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "asd_draft_sample_workspace_bytes": (_sz, [_i, _i, _i]),
-    "asd_debug_draft_groups": (_i, [_i]),
     "asd_draft_sample": (_i, [_vp, _i64, _i, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "asd_lse_partial": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
     "asd_accept_from_partials": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
@@ -64,15 +61,13 @@ SIGNATURES = {
     "asd_linear": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
     "asd_linear_ex": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
     "asd_linear_partial": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp, _vp]),
-    "asd_debug_linear_slices": (_i, [_i, _i, _i]),
+    "asd_linear_slices": (_i, [_i, _i, _i]),
     "asd_rmsnorm": (_i, [_vp, _i64, _vp, _f, _i, _i, _i, _vp, _i64, _vp]),
     "asd_rope_kv_store": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "asd_attn_ragged": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
     "asd_silu_mul": (_i, [_vp, _i64, _i, _i, _i, _vp, _i64, _vp]),
     "asd_decoder_scratch_bytes": (_sz, [_vp, _i]),
     "asd_decoder_forward": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
-    "asd_debug_force_linear_slices": (_i, [_i]),
-    "asd_debug_linear_tall": (_i, [_i]),
     "asd_lm_head_partial": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _i, _i, _i, _i64, _f, _vp, _vp, _sz, _vp]),
     "asd_commit_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),
     "asd_logprob_stats": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
@@ -88,6 +83,18 @@ SIGNATURES = {
     "asd_predictor_stop": (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _i, _i64, _d, _d, _vp, _vp, _d,
                                 _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+# the TEST build's additional entry points (include/asd_hip.h, #ifdef ASD_TEST_HOOKS; lib/libasd_hip_test.so)
+HOOK_SIGNATURES = {
+    "asd_debug_verify_withhold": (_i, [_i]),
+    "asd_debug_residual_groups": (_i, [_i]),
+    "asd_debug_draft_groups": (_i, [_i]),
+    "asd_debug_draft_withhold": (_i, [_i]),
+    "asd_debug_force_linear_slices": (_i, [_i]),
+    "asd_debug_linear_tall": (_i, [_i]),
+}
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "libasd_hip_test.so")
 
 
 class VerifyOptions(C.Structure):
@@ -123,12 +130,54 @@ class AsdError(RuntimeError):
 
 _lock = threading.Lock()
 _lib = None
+_test_lib = None
+_override = threading.local()       # test suite only: the calling thread's wrappers go through the TEST build (use_test_library)
+
+
+def load_test_library() -> C.CDLL:
+    """dlopen lib/libasd_hip_test.so (the -DASD_TEST_HOOKS build: every product entry point + the asd_debug_* hooks), building
+    it in-tree on first use.  Test infrastructure: nothing in the package calls this."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    with _lock:
+        if _test_lib is None:
+            import importlib.util
+            load_library()                                       # torch's HIP runtime first (see below)
+            spec = importlib.util.spec_from_file_location("asd_amd_build", os.path.join(_HERE, "build.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.build_test_hooks()
+            lib = C.CDLL(TEST_LIB_PATH)
+            for name, (res, args) in list(SIGNATURES.items()) + list(HOOK_SIGNATURES.items()):
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _test_lib = lib
+    return _test_lib
+
+
+class use_test_library:
+    """with use_test_library() as lib: ... -- inside the block THIS thread's load_library() returns the TEST build, so the
+    package's wrappers launch its kernels and honour its asd_debug_* switches (called on `lib`).  Test infrastructure."""
+
+    def __enter__(self):
+        self._prev = getattr(_override, "lib", None)
+        _override.lib = load_test_library()
+        return _override.lib
+
+    def __exit__(self, *exc):
+        _override.lib = self._prev
+        return False
 
 
 def load_library() -> C.CDLL:
     """dlopen libasd_hip.so and attach the prototypes.  Raises if the library or a symbol is
     missing -- the caller must build it (`python adaptive-speculative-decoding_amd/build.py`)."""
     global _lib
+    ov = getattr(_override, "lib", None)
+    if ov is not None:
+        return ov
     if _lib is not None:
         return _lib
     with _lock:

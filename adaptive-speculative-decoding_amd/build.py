@@ -51,6 +51,12 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# The TEST build of the same sources: -DASD_TEST_HOOKS adds the asd_debug_* switches (process-global test / fault-injection hooks,
+# include/asd_hip.h) that the product library does not contain.  Only the translation units that host a hook are compiled a
+# second time; the others are linked from the product objects.
+TEST_LIB = os.path.join(LIBDIR, "libasd_hip_test.so")
+TEST_HOOK_SOURCES = ("verify_accept.hip", "residual_sample.hip", "draft_sample.hip", "lm_head_verify.hip")
+
 ASAN_LIB = os.path.join(LIBDIR, "libasd_hip_asan.so")
 ASAN_FLAGS = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-g"]
 
@@ -65,13 +71,23 @@ def build(force: bool = False, verbose: bool = False, asan: bool = False) -> str
     return _build(hipcc, objdir, lib, ASAN_FLAGS if asan else [], force, verbose)
 
 
-def _build(hipcc, OBJDIR, LIB, more, force, verbose) -> str:
+def build_test_hooks(force: bool = False, verbose: bool = False) -> str:
+    """lib/libasd_hip_test.so: the product objects, with the hook-hosting translation units recompiled under -DASD_TEST_HOOKS."""
+    build(force=force, verbose=verbose)            # the product objects the test library links
+    return _build(_hipcc(), os.path.join(LIBDIR, "obj_test"), TEST_LIB, ["-DASD_TEST_HOOKS"], force, verbose,
+                  only=TEST_HOOK_SOURCES, fallback_objdir=OBJDIR)
+
+
+def _build(hipcc, OBJDIR, LIB, more, force, verbose, only=None, fallback_objdir=None) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers += [os.path.join(INC, "asd_hip.h"), os.path.abspath(__file__)]
     objs, jobs = [], []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
+        if only is not None and src not in only:   # linked from another build's objects
+            objs.append(os.path.join(fallback_objdir, src.replace(".hip", ".o")))
+            continue
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
@@ -94,4 +110,7 @@ def _build(hipcc, OBJDIR, LIB, more, force, verbose) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, asan="--asan" in sys.argv))
+    if "--test-hooks" in sys.argv:
+        print(build_test_hooks(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    else:
+        print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, asan="--asan" in sys.argv))

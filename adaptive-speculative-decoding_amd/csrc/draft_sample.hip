@@ -434,6 +434,8 @@ struct DgParams {
     unsigned long long* small;    // per row: pairs[n_pad], mass[n_pad], mail[kDgMaxGroups][kDgMsgs][2]
     int n_pad;                // n_tiles rounded up to a whole 256-byte block of words
     int base_shift;           // key bits that carry no information for this dtype (bf16: 16, f16: 13, f32: 0)
+    uint32_t* status;         // the workspace's sticky status word (a wait that runs out or-s ASD_WS_LOST_HANDOFF into it)
+    int withhold1;            // test build (asd_debug_draft_withhold): 1 + (row * G + g) of the partner workgroup that never publishes its tile pairs; 0 = off
 };
 
 template <int DT, int TPW>
@@ -487,7 +489,8 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_group(const DgParams p) {
             tile_pair<DT>(q[j], d.c2, M, sw);
             if (lane == 0) {
                 if (leader) { u.pair.m[tile] = M; u.pair.s[tile] = sw; }
-                else dg_put(pairs_x + tile, (static_cast<unsigned long long>(__float_as_uint(sw)) << 32) | __float_as_uint(M));
+                else if (b * G + g + 1 != p.withhold1)
+                    dg_put(pairs_x + tile, (static_cast<unsigned long long>(__float_as_uint(sw)) << 32) | __float_as_uint(M));
             }
         }
     }
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_group(const DgParams p) {
     float m2 = kSentinel, s = 0.0f;
     if (leader) {
         for (int tile = t1 + t; tile < d.n_tiles; tile += kDrThreads) {     // the partners' tiles (the leader's run is [0, t1))
-            const unsigned long long v = dg_poll(pairs_x + tile, &lost);
+            const unsigned long long v = dg_poll(pairs_x + tile, &lost, p.status);
             dg_put(pairs_x + tile, 0ull);
             u.pair.m[tile] = __uint_as_float(static_cast<uint32_t>(v));
             u.pair.s[tile] = __uint_as_float(static_cast<uint32_t>(v >> 32));
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_group(const DgParams p) {
                    (static_cast<unsigned long long>(__float_as_uint(s)) << 32) | __float_as_uint(m2));
     } else {
         if (t == 0) {
-            const unsigned long long v = dg_poll(mail, &lost);
+            const unsigned long long v = dg_poll(mail, &lost, p.status);
             dg_put(mail, 0ull);
             bc[0] = v;
         }
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_group(const DgParams p) {
                 unsigned long long* out = hist_mine + lv * kDsDigits;     // a round has its own area: no word is reused inside a call
                 for (int i = t; i < bins; i += kDrThreads) dg_put(out + i, u.hist[i] | kDgValid);
                 if (t < 2) {                               // the decision's two words, polled side by side
-                    bc[t] = dg_poll(mail + 2 * (1 + lv) + t, &lost);
+                    bc[t] = dg_poll(mail + 2 * (1 + lv) + t, &lost, p.status);
                     dg_put(mail + 2 * (1 + lv) + t, 0ull);
                 }
                 __syncthreads();
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_group(const DgParams p) {
                     for (int q4 = 0; q4 < 4; ++q4) {
                         const int it = it0 + q4 * kDrThreads;
                         if (it < items) {
-                            if (v[q4] == 0ull) v[q4] = dg_poll(in[q4], &lost);      // still in flight: wait for this one
+                            if (v[q4] == 0ull) v[q4] = dg_poll(in[q4], &lost, p.status);      // still in flight: wait for this one
                             dg_put(in[q4], 0ull);
                             const int pg = 1 + it / bins;
                             const unsigned long long add = v[q4] & ~kDgValid;
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(kDrThreads) void k_draft_group(const DgParams p) {
         }
         if (!leader) return;
         for (int tile = t1 + t; tile < d.n_tiles; tile += kDrThreads) {
-            const unsigned long long v = dg_poll(mass_x + tile, &lost);
+            const unsigned long long v = dg_poll(mass_x + tile, &lost, p.status);
             dg_put(mass_x + tile, 0ull);
             tile_mass[tile] = __uint_as_float(static_cast<uint32_t>(v));
         }
@@ -744,7 +747,13 @@ ASD_EXPORT int asd_debug_draft_stamps(unsigned long long* out16) {
 #endif
 
 namespace {
+#ifdef ASD_TEST_HOOKS         // (process-global, not thread-safe: the TEST build of the library only)
 int g_debug_groups = 0;       // asd_debug_draft_groups (tests only): force the workgroups per row; 0 = heuristic
+int g_debug_draft_withhold = -1;   // asd_debug_draft_withhold: fault injection for the hand-off tests
+#else
+constexpr int g_debug_groups = 0;
+constexpr int g_debug_draft_withhold = -1;
+#endif
 
 struct DgLayout {
     size_t hist_bytes, small_bytes;
@@ -780,19 +789,28 @@ void launch_group(const DgParams& p, int tpw, hipStream_t st) {
 }
 }  // namespace
 
+#ifdef ASD_TEST_HOOKS
 /* tests only: force the number of workgroups a row is spread over (1, 2, 4, ... 32; -1 = k_draft_row, the one-workgroup
  * streaming form; 0 = heuristic).  Results must not depend on it. */
 ASD_EXPORT int asd_debug_draft_groups(int groups) {
     g_debug_groups = groups;
     return ASD_OK;
 }
+/* tests only: in the asd_draft_sample calls that follow, partner workgroup g (>= 1) of row b, index = b * G + g with G the
+ * launch's workgroups per row, does not publish its tile pairs: the leader's bounded wait must end in tok = -1 / lp = NaN for
+ * THAT row and ASD_WS_LOST_HANDOFF in the workspace's status word.  index < 0 = off. */
+ASD_EXPORT int asd_debug_draft_withhold(int index) {
+    g_debug_draft_withhold = index < 0 ? -1 : index;
+    return ASD_OK;
+}
+#endif
 
 ASD_EXPORT size_t asd_draft_sample_workspace_bytes(int B, int V, int dtype) {
     const int esz = dtype_size(dtype);
     if (B <= 0 || V <= 0 || esz == 0) return 256;
     const size_t nvec = (static_cast<size_t>(V) * esz + 15) / 16;
     const DgLayout l = dg_layout(B, static_cast<int>((nvec + 63) / 64));
-    return round_up(l.hist_bytes + l.small_bytes, 256);
+    return kWorkspaceHeaderBytes + round_up(l.hist_bytes + l.small_bytes, 256);
 }
 
 ASD_EXPORT int asd_draft_sample(const void* logits, int64_t ld, int dtype, const float* r, int B, int V,
@@ -819,15 +837,18 @@ ASD_EXPORT int asd_draft_sample(const void* logits, int64_t ld, int dtype, const
     // few rows: spread every row over G workgroups (the workspace carries their mailboxes; without one, or with a row too
     // long for the registers of its workgroups, one streaming workgroup per row)
     const DgLayout l = dg_layout(B, p.n_tiles);
-    const bool have_ws = workspace && aligned_to(workspace, 256) && workspace_bytes >= l.hist_bytes + l.small_bytes;
+    const bool have_ws = workspace && aligned_to(workspace, 256) && workspace_bytes >= kWorkspaceHeaderBytes + l.hist_bytes + l.small_bytes;
     const int G = g_debug_groups < 0 ? 0 : choose_groups(B, p.n_tiles, current_device_cus(), have_ws);
     if (G >= 1) {
         DgParams q{};
         q.d = p;
         q.G = G;
-        q.hist_x = static_cast<unsigned long long*>(workspace);
-        q.small = have_ws ? reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + l.hist_bytes) : nullptr;
+        char* const body = have_ws ? static_cast<char*>(workspace) + kWorkspaceHeaderBytes : nullptr;    // (behind the status block)
+        q.status = have_ws ? static_cast<uint32_t*>(workspace) : nullptr;
+        q.hist_x = reinterpret_cast<unsigned long long*>(body);
+        q.small = have_ws ? reinterpret_cast<unsigned long long*>(body + l.hist_bytes) : nullptr;
         q.n_pad = l.n_pad;
+        q.withhold1 = g_debug_draft_withhold + 1;
         q.base_shift = dtype == ASD_DTYPE_BF16 ? 16 : (dtype == ASD_DTYPE_F16 ? 13 : 0);
         const int tpw = tiles_per_wave(p.n_tiles, G);
         switch (dtype) {

@@ -1385,7 +1385,15 @@ ASD_EXPORT int asd_lm_head_pack_weights(const void* weight, int64_t ld_w, int dt
 // resident) and k_linear_reduce -- or, inside asd_decoder_forward, the kernel that consumes the product (asd_linear_partial) --
 // adds them in slice order (bit-reproducible), adds bias and residual and rounds once.
 namespace {
+// test / lab switches: process-global and not thread-safe, so they exist in the TEST build of the library only
+// (-DASD_TEST_HOOKS -> lib/libasd_hip_test.so); the product library has the constants
+#ifdef ASD_TEST_HOOKS
 int g_linear_tall = 1;     // asd_debug_linear_tall(0): 256 < M <= 288 as 256 + 32 rows (A/B measurements)
+int g_force_linear_slices = 0;
+#else
+constexpr int g_linear_tall = 1;
+constexpr int g_force_linear_slices = 0;
+#endif
 struct LinearPlan {
     int kind;        // 0 skinny, 1 tile, 2 quad, 3 tall (one 288-row block)
     int k_slices;
@@ -1461,14 +1469,12 @@ ASD_EXPORT size_t asd_linear_workspace_bytes(int M, int N, int D) {
     return round_up(slabs, 256) + 256;
 }
 
-ASD_EXPORT int asd_debug_linear_slices(int M, int N, int D) {      // the plan's slice count (tests, tools)
+ASD_EXPORT int asd_linear_slices(int M, int N, int D) {      // the plan's slice count (a pure query: sizing, tests, tools)
     if (M <= 0 || N <= 0 || D <= 0 || D % kSuper != 0) return 0;
     return linear_plan(M, N, D).k_slices;
 }
 
-namespace {
-int g_force_linear_slices = 0;
-}
+#ifdef ASD_TEST_HOOKS
 ASD_EXPORT int asd_debug_linear_tall(int on) {            // returns the previous value
     const int old = g_linear_tall;
     g_linear_tall = on < 0 ? 0 : (on > 2 ? 2 : on);
@@ -1479,6 +1485,7 @@ ASD_EXPORT int asd_debug_force_linear_slices(int k) {      // 0: the plan's own 
     g_force_linear_slices = k < 0 ? 0 : k;
     return old;
 }
+#endif
 
 namespace {
 // k_slices_out != NULL: a sliced plan stops after the product -- the f32 partials stay in `workspace` as [k_slices][M][N]

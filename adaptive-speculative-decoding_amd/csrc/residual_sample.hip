@@ -340,6 +340,7 @@ struct RgParams {
     RsParams r;
     int G, n_pad;
     unsigned long long* small;       // per sequence: pairs_t[n_pad], pairs_d[n_pad], mass[n_pad], mail[kDgMaxGroups][2]
+    uint32_t* status;                // the workspace's sticky status word
 };
 
 template <int DT, int TPW>
@@ -406,8 +407,8 @@ __global__ __launch_bounds__(kDrThreads) void k_residual_group(const RgParams q)
     float mt, st, md, sd;
     if (leader) {
         for (int tile = t1 + t; tile < p.n_tiles; tile += kDrThreads) {
-            const unsigned long long a = dg_poll(pt_x + tile, &lost);
-            const unsigned long long c = dg_poll(pd_x + tile, &lost);
+            const unsigned long long a = dg_poll(pt_x + tile, &lost, q.status);
+            const unsigned long long c = dg_poll(pd_x + tile, &lost, q.status);
             dg_put(pt_x + tile, 0ull);
             dg_put(pd_x + tile, 0ull);
             tm[tile] = __uint_as_float(static_cast<uint32_t>(a));
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(kDrThreads) void k_residual_group(const RgParams q)
         }
     } else {
         if (t < 2) {
-            bc[t] = dg_poll(mail + t, &lost);
+            bc[t] = dg_poll(mail + t, &lost, q.status);
             dg_put(mail + t, 0ull);
         }
         __syncthreads();
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kDrThreads) void k_residual_group(const RgParams q)
     }
     if (!leader) return;
     for (int tile = t1 + t; tile < p.n_tiles; tile += kDrThreads) {
-        const unsigned long long v = dg_poll(mass_x + tile, &lost);
+        const unsigned long long v = dg_poll(mass_x + tile, &lost, q.status);
         dg_put(mass_x + tile, 0ull);
         tiles[tile] = make_float2(__uint_as_float(static_cast<uint32_t>(v)), __uint_as_float(static_cast<uint32_t>((v & ~kDgValid) >> 32)));
     }
@@ -496,7 +497,11 @@ inline int rs_splits(int B, int n_tiles, int cus) {
 using namespace asd;
 
 namespace {
+#ifdef ASD_TEST_HOOKS          // (process-global, not thread-safe: the TEST build of the library only)
 int g_debug_rs_groups = 0;     // asd_debug_residual_groups (tests only): force the workgroups per sequence; 0 = heuristic, -1 = never the group form
+#else
+constexpr int g_debug_rs_groups = 0;
+#endif
 struct RgLayout {
     size_t legacy_bytes, small_bytes;
     int n_pad;
@@ -515,15 +520,17 @@ ASD_EXPORT size_t asd_residual_sample_workspace_bytes(int B, int V, int dtype) {
     if (B <= 0 || V <= 0 || esz == 0) return 256;
     const size_t nvec = (static_cast<size_t>(V) * esz + 15) / 16;
     const RgLayout l = rg_layout(B, (nvec + 63) / 64);
-    return l.legacy_bytes + round_up(l.small_bytes, 256);
+    return kWorkspaceHeaderBytes + l.legacy_bytes + round_up(l.small_bytes, 256);
 }
 
+#ifdef ASD_TEST_HOOKS
 /* tests only: force the workgroups a sequence's rows are spread over (1 ... 32; -1 = the multi-launch / one-workgroup forms;
  * 0 = heuristic). */
 ASD_EXPORT int asd_debug_residual_groups(int groups) {
     g_debug_rs_groups = groups;
     return ASD_OK;
 }
+#endif
 
 namespace {
 int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, int64_t ld_d, const void* bonus_logits,
@@ -551,8 +558,9 @@ int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, in
     p.nvec = static_cast<int>(static_cast<int64_t>(V) * esz / 16);
     p.n_tiles = (p.nvec + 63) / 64;
     p.S = rs_splits(B, p.n_tiles, current_device_cus());
-    p.partial = static_cast<float4*>(workspace);
-    p.tiles = reinterpret_cast<float2*>(static_cast<char*>(workspace) + round_up(static_cast<size_t>(B) * 32 * sizeof(float4), 256));
+    char* const body = static_cast<char*>(workspace) + kWorkspaceHeaderBytes;       // (behind the status block)
+    p.partial = reinterpret_cast<float4*>(body);
+    p.tiles = reinterpret_cast<float2*>(body + round_up(static_cast<size_t>(B) * 32 * sizeof(float4), 256));
     p.token = token;
     p.d_thr = d_threshold;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -560,7 +568,7 @@ int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, in
     // part of the workspace and must have been zeroed once: asd_workspace_init)
     {
         const RgLayout l = rg_layout(B, static_cast<size_t>(p.n_tiles));
-        const bool have_ws = workspace_bytes >= l.legacy_bytes + l.small_bytes && p.n_tiles <= kDrMaxTiles;
+        const bool have_ws = workspace_bytes >= kWorkspaceHeaderBytes + l.legacy_bytes + l.small_bytes && p.n_tiles <= kDrMaxTiles;
         int G = 0;
         if (have_ws && g_debug_rs_groups >= 0 && B <= 64) {
             const int cus = current_device_cus();
@@ -575,7 +583,8 @@ int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, in
                 q.r = p;
                 q.G = G;
                 q.n_pad = l.n_pad;
-                q.small = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + l.legacy_bytes);
+                q.small = reinterpret_cast<unsigned long long*>(body + l.legacy_bytes);
+                q.status = static_cast<uint32_t*>(workspace);
                 const dim3 grid(static_cast<unsigned>(G), static_cast<unsigned>(B)), block(kDrThreads);
 #define ASD_LAUNCH_RG(DT)                                                                                 \
     do {                                                                                                  \

@@ -183,15 +183,23 @@ constexpr unsigned long long kDgValid = 1ull << 63;
 
 // bounded wait for a mailbox word (non-zero = published).  `lost` (LDS) is raised by the first wait that runs out and makes
 // every later wait of the workgroup return at once: a row whose partner never shows up costs ONE timeout, not one per word.
-__device__ __forceinline__ unsigned long long dg_poll(unsigned long long* slot, volatile int* lost) {
+// `status`: the workspace's sticky status word (its first 32 bits; include/asd_hip.h, asd_workspace_status) -- the wait that runs
+// out or-s ASD_WS_LOST_HANDOFF into it, so that the host learns of the loss at its next synchronisation: the poisoned outputs
+// (tok = -1, lp = NaN) say WHICH row, the status word says THAT the workspace is no longer all-zero (the late word will never be
+// handed back empty) and must be re-initialised before its next use.
+__device__ __forceinline__ unsigned long long dg_poll(unsigned long long* slot, volatile int* lost, uint32_t* status) {
     unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int spins = 0; v == 0ull && spins < kDgSpinLimit && !*lost; ++spins) {
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (v == 0ull) *lost = 1;
+    if (v == 0ull) {
+        if (!*lost && status) __hip_atomic_fetch_or(status, static_cast<uint32_t>(ASD_WS_LOST_HANDOFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lost = 1;
+    }
     return v;
 }
+constexpr size_t kWorkspaceHeaderBytes = 256;   // every hand-off workspace begins with this block: u32 status word at +0, rest reserved
 __device__ __forceinline__ void dg_put(unsigned long long* slot, unsigned long long v) {
     __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

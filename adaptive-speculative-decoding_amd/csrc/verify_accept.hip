@@ -753,7 +753,11 @@ int launch_threads(const VerifyParams& p, int64_t grid, hipStream_t st, const Ge
     }
 }
 
-int g_debug_withhold = -1;   // asd_debug_verify_withhold (tests only; not thread-safe by design)
+#ifdef ASD_TEST_HOOKS        // (process-global, not thread-safe: the TEST build of the library only)
+int g_debug_withhold = -1;   // asd_debug_verify_withhold: fault injection for the hand-off tests
+#else
+constexpr int g_debug_withhold = -1;
+#endif
 
 int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_bytes, void* stream, Geometry g) {
     p.withhold1 = g_debug_withhold + 1;
@@ -988,12 +992,14 @@ ASD_EXPORT int asd_verify_accept_fused(const void* logits, int dtype, int64_t ld
                                       prefix_rule, theta, score, k_star, stop, thr_stop, stats, nullptr, stream);
 }
 
+#ifdef ASD_TEST_HOOKS
 /* tests only: the workgroup with linear index row * S + split (S = splits of the launch) does not publish its hand-off
  * slot in the following launches (its row / sequence must come back poisoned, never silently wrong); -1 = off. */
 ASD_EXPORT int asd_debug_verify_withhold(int index) {
     asd::g_debug_withhold = index < 0 ? -1 : index;
     return ASD_OK;
 }
+#endif
 
 ASD_EXPORT int asd_verify_accept(const void* logits, int dtype, int64_t ld_row, const int32_t* tok,
                                  const float* lp_draft, const float* u, int B, int K, int V, float* lp_target,

@@ -57,7 +57,6 @@ class HipOps:
         self._lock = threading.Lock()
         self.pack_lm_head = bool(pack_lm_head)
         self.profile = bool(profile)
-        self._last = None                    # (event0, event1, algorithmic bytes, what)
 
     def _timed_step(self, what, nbytes, fn):
         if not self.profile:
@@ -66,14 +65,15 @@ class HipOps:
         e0.record()
         out = fn()
         e1.record()
-        self._last = (e0, e1, int(nbytes), what)
+        self._tls.last = (e0, e1, int(nbytes), what)       # per calling thread, like the scratch: stats() reports THIS thread's step
         return out
 
     def stats(self):
-        """{"kernel_us", "hbm_gbps", "step"} of the last profiled verify step (waits for it to finish); {} if none."""
-        if self._last is None:
+        """{"kernel_us", "hbm_gbps", "step"} of the last verify step the CALLING THREAD profiled (waits for it to finish); {} if none."""
+        last = getattr(self._tls, "last", None)
+        if last is None:
             return {}
-        e0, e1, nbytes, what = self._last
+        e0, e1, nbytes, what = last
         e1.synchronize()
         us = 1e3 * e0.elapsed_time(e1)
         return {"kernel_us": us, "hbm_gbps": nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0, "step": what,
@@ -85,6 +85,31 @@ class HipOps:
         if d is None:
             d = self._tls.ws = {}
         return d
+
+    def check_status(self) -> None:
+        """The sticky status words (include/asd_hip.h: asd_workspace_status) of every hand-off workspace the CALLING THREAD has
+        used -- verify workspaces, the draft and residual samplers' mailboxes -- in ONE synchronising read.  A kernel whose bounded
+        wait for a hand-off word ran out poisoned what depended on it (lp_t = NaN and reject; score = NaN, k* = L - 1; tok = -1) and
+        raised the word: this raises kernels.LostHandoffError for it, after re-initialising every workspace that reported a loss
+        (the late word was never handed back empty, so such a workspace is no longer all-zero between calls).  The loop drivers
+        call it once per step, at a point where they synchronise anyway."""
+        wss = [w for w in self._ws.values() if isinstance(w, self.K._StatusWorkspace)]
+        if not wss:
+            return
+        by_dev = {}
+        for w in wss:
+            by_dev.setdefault(w.buf.device, []).append(w)
+        dirty = []
+        for group in by_dev.values():
+            words = torch.stack([w.status_word for w in group])
+            if int(words.max().item()) != 0:
+                dirty += [w for w, v in zip(group, words.tolist()) if v != 0]
+        if dirty:
+            names = ", ".join(f"{type(w).__name__} (status 0x{int(w.status_word.item()):x})" for w in dirty)
+            for w in dirty:
+                w.reset()
+            raise self.K.LostHandoffError(f"a hand-off word never arrived in: {names}; the affected results were poisoned and the "
+                                          "workspaces have been re-initialised")
 
     def _workspace(self, B, K, V, dtype, device):
         key = (B, K, str(dtype), str(device))

@@ -26,6 +26,11 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# test infrastructure: `with kernels.test_hooks() as lib:` routes THIS thread's calls through lib/libasd_hip_test.so (the
+# -DASD_TEST_HOOKS build, which alone has the asd_debug_* switches; `lib` is its ctypes handle)
+test_hooks = B.use_test_library
+
+
 def _dev(t: torch.Tensor, name: str, dtype=None) -> int:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise ValueError(f"{name} must be a CUDA (HIP) tensor; this package has no CPU path")
@@ -561,7 +566,7 @@ def _rows(t: torch.Tensor, name: str) -> Tuple[int, int]:
     return t.data_ptr(), t.stride(-2)
 
 
-class ResidualSampler:
+class ResidualSampler(_StatusWorkspace):
     """asd_residual_sample with its workspace: the token each sequence commits after its accepted prefix."""
 
     def __init__(self, B_: int, V: int, dtype: torch.dtype = torch.bfloat16, device: Optional[torch.device] = None):
@@ -569,7 +574,7 @@ class ResidualSampler:
         # scratch of the multi-launch form + the mailboxes of the group form (B <= 64): zeroed ONCE, handed back empty by every call
         self.bytes = int(_lib().asd_residual_sample_workspace_bytes(B_, V, _DTYPE_CODE[dtype]))
         self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device or torch.device("cuda"))
-        B.check("asd_workspace_init", _lib().asd_workspace_init(self.buf.data_ptr(), self.bytes, _stream()))
+        self.reset()
 
     def __call__(self, t_logits: torch.Tensor, d_logits: torch.Tensor, n_acc: torch.Tensor, r: torch.Tensor,
                  bonus_logits: Optional[torch.Tensor] = None, inv_temperature: float = 1.0,
@@ -602,7 +607,7 @@ class DraftDraw:
     thr: torch.Tensor   # [B] f32  nucleus threshold logit (-inf: no truncation)
 
 
-class DraftSampler:
+class DraftSampler(_StatusWorkspace):
     """X1: asd_draft_sample with its workspace -- one call proposes the next token of every sequence from the
     draft tier's next-token logits [B, V]: temperature and top-p folded in, inverse-CDF draw from caller-supplied
     uniforms, log q(tok) for the verify step, nucleus threshold for the exact residual."""
@@ -612,7 +617,7 @@ class DraftSampler:
         # mailboxes of the workgroups a row is spread over (B <= 128): zeroed ONCE, handed back empty by every call
         self.bytes = int(_lib().asd_draft_sample_workspace_bytes(B_, V, _DTYPE_CODE[dtype]))
         self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device or torch.device("cuda"))
-        B.check("asd_workspace_init", _lib().asd_workspace_init(self.buf.data_ptr(), self.bytes, _stream()))
+        self.reset()
 
     def __call__(self, logits: torch.Tensor, r: torch.Tensor, inv_temperature: float = 1.0, top_p: float = 1.0,
                  out: Optional[DraftDraw] = None) -> DraftDraw:

@@ -551,6 +551,14 @@ class HierarchyTrace:
         return [c / tot for c in self.tier_counts]
 
 
+def _check_status(ops) -> None:
+    """Once per step, where the drivers synchronise anyway: a kernel that lost a hand-off poisoned its outputs AND raised its
+    workspace's sticky status word (HipOps.check_status raises kernels.LostHandoffError); the oracle-backed test ops have none."""
+    chk = getattr(ops, "check_status", None)
+    if chk is not None:
+        chk()
+
+
 def _account(tr: HierarchyTrace, L: int, final: FinalMsg, verdicts) -> None:
     t = final.tier.cpu().numpy()
     for s in range(L):
@@ -593,6 +601,7 @@ def generate_hierarchical(draft: DraftRole, tiers: Sequence[VerifyRole], max_ste
         for t in tiers:
             t.commit(dm, final)
         tr.verified_tokens += int(draft.st.seq_len.sum().item()) - before
+        _check_status(draft.ops)
         _account(tr, L, final, verdicts)
         if keep_inputs:
             tr.records.append(rec)
@@ -877,6 +886,7 @@ def run_hierarchical_rank(rank: int, placement: Placement, draft: Optional[Draft
         for t in tiers.values():
             t.commit(dm, final)
         tr.verified_tokens += int(state.seq_len.sum().item()) - before
+        _check_status(draft.ops if draft is not None else next(iter(tiers.values())).ops)
         _account(tr, L, final, verdicts)
         if keep_inputs:
             tr.records.append(rec)
@@ -1103,6 +1113,7 @@ def run_sharded_target_rank(rank: int, world: int, draft: DraftRole, target: Sha
         draft.commit(dm_l, final_l)
         target.commit(dm_l, final_l)
         tr.verified_tokens += int(target.st.seq_len.sum().item()) - before
+        _check_status(target.ops)
         tr.tier_counts[1] += b1 - b0
         tr.tier_calls[1] += b1 - b0
         tr.steps += 1

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define ASD_VERSION_MAJOR 0
-#define ASD_VERSION_MINOR 2
+#define ASD_VERSION_MINOR 3
 #define ASD_VERSION_PATCH 0
 
 typedef enum asd_status {
@@ -227,10 +227,8 @@ int asd_linear_ex(const void* x, int64_t ld_x, const void* w, int64_t ld_w, cons
 int asd_linear_partial(const void* x, int64_t ld_x, const void* w, int64_t ld_w, const void* bias, const void* residual,
                        int64_t ld_res, int dtype, int M, int N, int D, void* y, int64_t ld_y, void* workspace,
                        size_t workspace_bytes, void* stream, int* k_slices /*out*/);
-/* test hooks: the reduction slices the launcher would use; force a count (0 = the launcher's own choice; process-wide) */
-int asd_debug_linear_slices(int M, int N, int D);
-int asd_debug_force_linear_slices(int k_slices);   /* returns the previous value */
-int asd_debug_linear_tall(int on);                 /* 256 < M <= 288 as one 288-row block (1, default) or as 256 + 32 rows (0) */
+/* host: the number of reduction slices the launcher uses for this product (1 = unsliced; 0 = unsupported shape) */
+int asd_linear_slices(int M, int N, int D);
 
 /* ------------------------------------------------------------------------------------------
  * X3, continued: the rest of a decoder layer around the projections, for the M = B * T positions a tier is fed in one pass
@@ -444,12 +442,6 @@ size_t asd_draft_sample_workspace_bytes(int B, int V, int dtype);
 int asd_draft_sample(const void* logits, int64_t ld, int dtype, const float* r /*[B]*/, int B, int V,
                      float inv_temperature, float top_p, int32_t* tok /*[B] out*/, float* lp /*[B] out, may be NULL*/,
                      float* nucleus_logit /*[B] out, may be NULL*/, void* workspace, size_t workspace_bytes, void* stream);
-/* Test hook: force the workgroups per sequence of the following asd_residual_sample[_ex] calls (1 ... 32; -1 = never the group
- * form; 0 = heuristic). */
-int asd_debug_residual_groups(int groups);
-/* Test hook (host state; no reference counterpart): force the workgroups per row of the following asd_draft_sample calls
- * (1, 2, 4 ... 32; -1 = the one-workgroup streaming form; 0 = heuristic).  Results must not depend on it. */
-int asd_debug_draft_groups(int groups);
 
 /* N1, second form: asd_verify_accept with the epilogue of asd_predictor_stop run INSIDE the same
  * launch by the wave that completes each sequence (lp = the kernel's own lp_target, all K
@@ -485,12 +477,34 @@ int asd_verify_accept_fused_ex(const void* logits, int dtype, int64_t ld_row,
                                float* score, int32_t* k_star, uint8_t* stop, uint8_t* thr_stop, double* stats,
                                const asd_verify_options* opt /*host, may be NULL*/, void* stream);
 
-/* Test hook (host state, not thread-safe; no reference counterpart): in the verify launches that follow, the workgroup
- * with linear index row * S + split (S = the launch's splits per row) does not publish its hand-off slot.  The kernel's
- * bounded wait must then POISON the affected outputs -- lp_target = NaN and accept = 0 for the row (split rows), score =
- * NaN / k_star = L - 1 / stop = 0 for the sequence (in-kernel epilogue) -- never return a plausible wrong value.
- * index < 0 switches the hook off. */
+#ifdef ASD_TEST_HOOKS
+/* ------------------------------------------------------------------------------------------
+ * TEST HOOKS -- not part of the product library.  They are process-global switches (not thread-safe next to the
+ * reference's 100-thread caller, src/serving/pipeline.py:83), so libasd_hip.so does not contain them at all: they exist in
+ * the separate TEST build of the same sources (-DASD_TEST_HOOKS -> lib/libasd_hip_test.so, build.py), which the test-suite
+ * loads next to the product library for the few tests that need them (kernels.test_hooks()).
+ * ---------------------------------------------------------------------------------------- */
+/* force the reduction slices of asd_linear* (0 = the launcher's own choice); returns the previous value */
+int asd_debug_force_linear_slices(int k_slices);
+/* 256 < M <= 288 as one 288-row block (1, default) or as 256 + 32 rows (0); returns the previous value */
+int asd_debug_linear_tall(int on);
+/* force the workgroups per sequence of the following asd_residual_sample[_ex] calls (1 ... 32; -1 = never the group form;
+ * 0 = heuristic) */
+int asd_debug_residual_groups(int groups);
+/* force the workgroups per row of the following asd_draft_sample calls (1, 2, 4 ... 32; -1 = the one-workgroup streaming
+ * form; 0 = heuristic).  Results must not depend on it. */
+int asd_debug_draft_groups(int groups);
+/* fault injection: in the asd_draft_sample calls that follow, partner workgroup g >= 1 of row b (index = b * G + g, G = the
+ * launch's workgroups per row) does not publish its tile pairs.  The leader's bounded wait (~0.5 s) must end in tok = -1 /
+ * lp = nucleus_logit = NaN for that row and ASD_WS_LOST_HANDOFF in the workspace's status word.  index < 0 = off. */
+int asd_debug_draft_withhold(int index);
+/* fault injection: in the verify launches that follow, the workgroup with linear index row * S + split (S = the launch's
+ * splits per row) does not publish its hand-off slot.  The kernel's bounded wait must then POISON the affected outputs --
+ * lp_target = NaN and accept = 0 for the row (split rows), score = NaN / k_star = L - 1 / stop = 0 for the sequence
+ * (in-kernel epilogue) -- and raise ASD_WS_LOST_HANDOFF in the workspace's status word; never return a plausible wrong
+ * value.  index < 0 switches the hook off. */
 int asd_debug_verify_withhold(int index);
+#endif /* ASD_TEST_HOOKS */
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ from tests.helpers import encode_logits, to_device_logits  # noqa: E402
 
 
 def main():
+    hooks = K.test_hooks().__enter__()          # the TEST build of the library for the whole program (asd_debug_draft_groups)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
     n_thr = n_tok = n_res = 0
@@ -43,11 +44,11 @@ def main():
         ref = O.draft_sample(store, dtype, r, B, V, inv_t, top_p)
         lg = to_device_logits(store, dtype).view(B, V)
         groups = int(rng.choice([0, 0, -1, 1, 2, 4, 8, 16, 32]))            # 0: heuristic; -1: the streaming form; else forced
-        K._lib().asd_debug_draft_groups(groups if groups <= 0 or B * groups <= 256 else 0)
+        hooks.asd_debug_draft_groups(groups if groups <= 0 or B * groups <= 256 else 0)
         samp = K.DraftSampler(B, V, lg.dtype)
         d = samp(lg, torch.from_numpy(r).cuda(), inv_t, top_p)
         torch.cuda.synchronize()
-        K._lib().asd_debug_draft_groups(0)
+        hooks.asd_debug_draft_groups(0)
         assert int(samp.buf.count_nonzero()) == 0, (it, "workspace not handed back empty", B, V, groups)
         tok, lp, thr = d.tok.cpu().numpy(), d.lp.cpu().numpy(), d.thr.cpu().numpy()
         okp = ref["margin_p"] > 1e-5

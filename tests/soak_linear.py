@@ -18,7 +18,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
-    lib = K_._lib()
+    lib = K_.test_hooks().__enter__()          # the TEST build of the library for the whole program (asd_debug_force_linear_slices)
     ws = K_.LinearWorkspace("cuda")
     worst = 0.0
     for c in range(cases):

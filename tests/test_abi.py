@@ -10,10 +10,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(hooks: bool = False):
+    """Entry points include/asd_hip.h declares: the product's (outside `#ifdef ASD_TEST_HOOKS`) or the test hooks (inside)."""
     text = open(os.path.join(ROOT, "include", "asd_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(asd_[a-z0-9_]+)\s*\(", text)))
+    inside = "".join(re.findall(r"#ifdef ASD_TEST_HOOKS(.*?)#endif", text, flags=re.S))
+    outside = re.sub(r"#ifdef ASD_TEST_HOOKS.*?#endif", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(asd_[a-z0-9_]+)\s*\(", inside if hooks else outside)))
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("asd_")})
 
 
 def test_header_symbols_exported_and_bound():
@@ -26,10 +35,27 @@ def test_header_symbols_exported_and_bound():
     assert sorted(_binding.SIGNATURES) == names
 
 
+def test_the_product_library_exports_no_test_hook():
+    """The asd_debug_* switches are process-global (not thread-safe next to a 100-thread caller, src/serving/pipeline.py:83):
+    they live in the TEST build of the library only.  libasd_hip.so exports exactly the header's product entry points."""
+    from asd_amd import _binding
+    _binding.load_library()
+    exported = _exported(_binding.LIB_PATH)
+    assert not [n for n in exported if n.startswith("asd_debug_")], exported
+    assert exported == _declared()
+    hooks = _declared(hooks=True)
+    assert hooks and all(n.startswith("asd_debug_") for n in hooks) and sorted(_binding.HOOK_SIGNATURES) == hooks
+    # ... and the test build (hipcc cross-compiles it here) exports the product's entry points plus exactly those hooks
+    test_lib = _binding.load_test_library()
+    assert _exported(_binding.TEST_LIB_PATH) == sorted(_declared() + hooks)
+    for n in hooks:
+        assert hasattr(test_lib, n)
+
+
 def test_version_and_status_strings():
     from asd_amd import _binding
     lib = _binding.load_library()
-    assert lib.asd_version() == 200       # 0.2.0: sampler workspaces carry mailboxes (zero-initialised once)
+    assert lib.asd_version() == 300       # 0.3.0: every hand-off workspace starts with a status block; the asd_debug_* hooks left the product
     assert lib.asd_status_string(0) == b"ok"
     assert b"workspace" in lib.asd_status_string(-3)
     assert lib.asd_verify_accept_workspace_bytes(32, 8, 152064, 1) % 256 == 0
@@ -86,10 +112,10 @@ def test_linear_plan_is_sane_without_a_gpu():
     lib = B.load_library()
     for (M, N, D) in [(1, 3584, 3584), (32, 3584, 3584), (32, 152064, 3584), (64, 512, 64), (99, 8192, 29568), (207, 59136, 8192),
                       (288, 5120, 27648), (288, 55296, 5120), (992, 3584, 3584), (1024, 152064, 8192)]:
-        k = lib.asd_debug_linear_slices(M, N, D)
+        k = lib.asd_linear_slices(M, N, D)
         assert 1 <= k <= min(32, D // 64), (M, N, D, k)
         need = lib.asd_linear_workspace_bytes(M, N, D)
         assert need >= (k * M * N * 4 if k > 1 else 0) and need <= k * M * N * 4 + 1024
-    assert lib.asd_debug_linear_slices(32, 59136, 8192) == 1            # 231 column blocks on 256 CUs: one round, no slicing
-    assert lib.asd_debug_linear_slices(32, 3584, 3584) > 1              # 14 column blocks
-    assert lib.asd_debug_linear_slices(32, 3584, 100) == 0 and lib.asd_linear_workspace_bytes(32, 3584, 100) == 0   # D % 64
+    assert lib.asd_linear_slices(32, 59136, 8192) == 1            # 231 column blocks on 256 CUs: one round, no slicing
+    assert lib.asd_linear_slices(32, 3584, 3584) > 1              # 14 column blocks
+    assert lib.asd_linear_slices(32, 3584, 100) == 0 and lib.asd_linear_workspace_bytes(32, 3584, 100) == 0   # D % 64

@@ -236,7 +236,7 @@ def test_decoder_forward_equals_the_composition_of_its_parts():
     want = torch.empty_like(x)
     _check(lib.asd_rmsnorm(x.data_ptr(), shape.hidden, lm.norm.weight.data_ptr(), shape.rms_eps, Bd.DTYPE_BF16, M, shape.hidden, want.data_ptr(), shape.hidden, None), "asd_rmsnorm")
     got = lm.forward_ragged(ids, pos0, 40, return_hidden=True)
-    assert lib.asd_debug_linear_slices(M, shape.hidden, shape.hidden) > 1           # the fused consumers really ran
+    assert lib.asd_linear_slices(M, shape.hidden, shape.hidden) > 1           # the fused consumers really ran
     assert torch.equal(got.view(M, shape.hidden), want)
 
 

@@ -250,22 +250,19 @@ def test_draft_sample_status_codes(K_):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # round 3: a row spread over G workgroups inside one launch (k_draft_group)
-def _set_groups(K_, g):
-    K_._lib().asd_debug_draft_groups(int(g))
-
-
 def _run_with_groups(K_, g, store, r, B, V, dtype, inv_t, top_p):
     import torch
-    try:
-        _set_groups(K_, g)
-        lg = to_device_logits(store, dtype).view(B, V)
-        samp = K_.DraftSampler(B, V, lg.dtype)
-        d = samp(lg, torch.from_numpy(r).cuda(), inv_t, top_p)
-        torch.cuda.synchronize()
-        assert int(samp.buf.count_nonzero()) == 0, "every mailbox word must be handed back empty"
-        return d.tok.cpu().numpy(), d.lp.cpu().numpy(), d.thr.cpu().numpy()
-    finally:
-        _set_groups(K_, 0)
+    with K_.test_hooks() as lib:                # the TEST build of the library: the product one has no asd_debug_* switches
+        try:
+            lib.asd_debug_draft_groups(int(g))
+            lg = to_device_logits(store, dtype).view(B, V)
+            samp = K_.DraftSampler(B, V, lg.dtype)
+            d = samp(lg, torch.from_numpy(r).cuda(), inv_t, top_p)
+            torch.cuda.synchronize()
+            assert int(samp.buf.count_nonzero()) == 0, "every mailbox word must be handed back empty (and the status word clean)"
+            return d.tok.cpu().numpy(), d.lp.cpu().numpy(), d.thr.cpu().numpy()
+        finally:
+            lib.asd_debug_draft_groups(0)
 
 
 @pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F16, O.DT_F32])
@@ -386,4 +383,59 @@ def test_group_kernel_in_a_hipgraph_and_across_batch_sizes(K_):
         ref = O.draft_sample(store, O.DT_BF16, r2, 32, V, inv_t, 0.9)
         ok = (ref["margin_p"] > 1e-5) & (ref["margin_r"] > 1e-5)
         assert np.array_equal(out.tok.cpu().numpy()[ok], ref["tok"][ok])
+    assert int(samp.buf.count_nonzero()) == 0
+
+
+def test_a_lost_hand_off_poisons_the_row_raises_the_status_word_and_the_sampler_recovers(K_):
+    """a timed-out mailbox hand-off must not only poison its row (tok = -1, lp = NaN) -- the workspace is then no
+    longer all-zero (the reader gave up: a word published late is never handed back empty), so the loss is REPORTED through the
+    workspace's sticky status word, the wrapper raises and re-initialises, and the next call on the same sampler is clean.
+    (asd_debug_draft_withhold exists in the TEST build of the library only.)"""
+    import torch
+    B, V = 8, 152064
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((B, V)) * 3).astype(np.float32)
+    store = encode_logits(x, O.DT_BF16)
+    r = rng.uniform(0, 1, B).astype(np.float32)
+    ref = O.draft_sample(store, O.DT_BF16, r, B, V, 1.0, 0.9)
+    lg = to_device_logits(store, O.DT_BF16).view(B, V)
+    rt = torch.from_numpy(r).cuda()
+    with K_.test_hooks() as lib:
+        samp = K_.DraftSampler(B, V, lg.dtype)
+        try:
+            lib.asd_debug_draft_groups(4)
+            lib.asd_debug_draft_withhold(5 * 4 + 2)                  # row 5, partner workgroup 2
+            d = samp(lg, rt, 1.0, 0.9)
+            torch.cuda.synchronize()
+        finally:
+            lib.asd_debug_draft_withhold(-1)
+        tok, lp = d.tok.cpu().numpy(), d.lp.cpu().numpy()
+        assert tok[5] == -1 and np.isnan(lp[5])                      # poisoned, not guessed
+        ok = np.arange(B) != 5
+        assert np.array_equal(tok[ok], ref["tok"][ok])               # the other rows are untouched
+        assert samp.status() == K_.B.WS_LOST_HANDOFF
+        with pytest.raises(K_.LostHandoffError):
+            samp.check()
+        assert samp.status() == 0 and int(samp.buf.count_nonzero()) == 0
+        d = samp(lg, rt, 1.0, 0.9)                                   # the same sampler, the same workspace: clean again
+        torch.cuda.synchronize()
+        lib.asd_debug_draft_groups(0)
+        assert np.array_equal(d.tok.cpu().numpy(), ref["tok"]) and samp.status() == 0
+
+
+def test_hipops_check_status_raises_once_for_a_lost_hand_off_and_reinitialises(K_):
+    """The loop drivers call HipOps.check_status() once per step: one synchronising read of every hand-off workspace of the
+    calling thread; a raised status word becomes LostHandoffError and the workspace is re-initialised."""
+    import torch
+    from asd_amd.distributed import HipOps
+    ops = HipOps()
+    B, V = 4, 32000
+    lg = (torch.randn((B, V), device="cuda") * 3).to(torch.bfloat16)
+    ops.draft_sample(lg, torch.rand((B,), device="cuda"), 1.0, 0.9)
+    ops.check_status()                                               # clean
+    samp = next(w for w in ops._ws.values() if isinstance(w, ops.K.DraftSampler))
+    samp.buf[:4].view(torch.int32).fill_(1)                          # what a kernel's timed-out wait does (ASD_WS_LOST_HANDOFF)
+    with pytest.raises(ops.K.LostHandoffError):
+        ops.check_status()
+    ops.check_status()                                               # re-initialised
     assert int(samp.buf.count_nonzero()) == 0

@@ -85,19 +85,19 @@ def test_linear_slice_counts_agree(M):
     """Forced reduction-slice counts (1 = no slabs, direct store) differ only in the f32 summation order."""
     from importlib import import_module
     K_ = import_module("adaptive-speculative-decoding_amd.kernels")
-    lib = K_._lib()
     x, w, b = _mk(M, 3584, 3584, torch.bfloat16, True, seed=11)
     ref = _ref(x, w, b)
     ws = K_.LinearWorkspace("cuda")
-    assert lib.asd_debug_linear_slices(M, 3584, 3584) > 1       # a 14-block matrix cannot fill the CUs unsliced
-    try:
-        for k in (1, 2, 7, 56):
-            lib.asd_debug_force_linear_slices(k)
-            ws.buf = torch.empty(56 * M * 3584 * 4 + 512, dtype=torch.uint8, device="cuda")
-            y = K_.linear(x, w, b, workspace=ws)
-            _check(y, ref, torch.bfloat16)
-    finally:
-        lib.asd_debug_force_linear_slices(0)
+    assert K_._lib().asd_linear_slices(M, 3584, 3584) > 1       # a 14-block matrix cannot fill the CUs unsliced
+    with K_.test_hooks() as lib:                # the TEST build of the library: the product one has no asd_debug_* switches
+        try:
+            for k in (1, 2, 7, 56):
+                lib.asd_debug_force_linear_slices(k)
+                ws.buf = torch.empty(56 * M * 3584 * 4 + 512, dtype=torch.uint8, device="cuda")
+                y = K_.linear(x, w, b, workspace=ws)
+                _check(y, ref, torch.bfloat16)
+        finally:
+            lib.asd_debug_force_linear_slices(0)
 
 
 def test_linear_argument_checks():
@@ -118,16 +118,16 @@ def test_linear_tall_form_and_two_block_form_agree():
     """256 < M <= 288 runs as ONE 288-row block (k_linear_tall); asd_debug_linear_tall(0) brings back 256 + 32 rows."""
     from importlib import import_module
     K_ = import_module("adaptive-speculative-decoding_amd.kernels")
-    lib = K_._lib()
     x, w, b = _mk(288, 7168, 5120, torch.bfloat16, True, seed=21)
     ref = _ref(x, w, b)
     ws = K_.LinearWorkspace("cuda")
     ws.buf = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     y_tall = K_.linear(x, w, b, workspace=ws)
-    prev = lib.asd_debug_linear_tall(0)
-    try:
-        y_two = K_.linear(x, w, b, workspace=ws)
-    finally:
-        lib.asd_debug_linear_tall(prev)
+    with K_.test_hooks() as lib:                # the TEST build of the library: the product one has no asd_debug_* switches
+        prev = lib.asd_debug_linear_tall(0)
+        try:
+            y_two = K_.linear(x, w, b, workspace=ws)
+        finally:
+            lib.asd_debug_linear_tall(prev)
     _check(y_tall, ref, torch.bfloat16)
     _check(y_two, ref, torch.bfloat16)

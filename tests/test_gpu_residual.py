@@ -95,16 +95,16 @@ def test_rows_must_be_whole_vectors(K_):
 # round 3: a sequence's two rows spread over G workgroups inside one launch (k_residual_group)
 def _residual_with_groups(K_, g, t, d, bo, n_acc, r, inv_t, thr=None):
     import torch
-    lib = K_._lib()
     B, V = t.shape[0], t.shape[2]
-    try:
-        lib.asd_debug_residual_groups(int(g))
-        samp = K_.ResidualSampler(B, V, t.dtype)
-        got = samp(t, d, n_acc, r, bo, inv_t, d_threshold=thr)
-        torch.cuda.synchronize()
-        return got.cpu().numpy(), samp
-    finally:
-        lib.asd_debug_residual_groups(0)
+    with K_.test_hooks() as lib:                # the TEST build of the library: the product one has no asd_debug_* switches
+        try:
+            lib.asd_debug_residual_groups(int(g))
+            samp = K_.ResidualSampler(B, V, t.dtype)
+            got = samp(t, d, n_acc, r, bo, inv_t, d_threshold=thr)
+            torch.cuda.synchronize()
+            return got.cpu().numpy(), samp
+        finally:
+            lib.asd_debug_residual_groups(0)
 
 
 @pytest.mark.parametrize("dtype", [O.DT_BF16, O.DT_F32, O.DT_F16])
@@ -145,8 +145,9 @@ def test_residual_group_kernel_matches_the_oracle_whatever_the_workgroups_per_se
             got, samp = _residual_with_groups(K_, g, t, d, bo, na, rr, inv_t, th)
             assert np.array_equal(got[ok], want[ok]), (g, use_thr)
             nvec = V * t.element_size() // 16
-            legacy = -(-B * 32 * 16 // 256) * 256 + -(-B * ((nvec + 63) // 64) * 8 // 256) * 256     # scratch of the multi-launch form
+            legacy = 256 + -(-B * 32 * 16 // 256) * 256 + -(-B * ((nvec + 63) // 64) * 8 // 256) * 256     # status block + scratch of the multi-launch form
             assert int(samp.buf[legacy:].count_nonzero()) == 0, "the mailboxes are handed back empty"
+            assert samp.status() == 0
             n_tiles = (nvec + 63) // 64
             if g > 0 and -(-(-(-n_tiles // g)) // 16) <= 5:          # the rows fit the registers of g workgroups: a group form ran
                 first = got if first is None else first

@@ -169,3 +169,39 @@ def test_get_stats_reports_the_last_verify_step_and_roctx_ranges_are_live():
     assert 5.0 < st["kernel_us"] < 200.0 and 400.0 < st["hbm_gbps"] < 8000.0, st
     assert np.array_equal(out[1].cpu().numpy(), c["ref"]["accept"])
     pipe.shutdown()
+
+
+def test_stats_report_the_calling_threads_own_step():
+    """HipOps documents itself re-entrant (one scratch set per calling thread): the profiled event pair is per thread too, so
+    stats() never reports another thread's step (round 3 kept ONE slot for all threads)."""
+    import threading
+    import torch
+    from asd_amd.distributed import HipOps
+    ops = HipOps(profile=True)
+    shapes = {"a": (8, 8, 32000), "b": (32, 4, 152064)}
+    got, errs = {}, []
+    barrier = threading.Barrier(2)
+
+    def work(name):
+        try:
+            Bn, Kn, Vn = shapes[name]
+            c = make_verify_case(Bn, Kn, Vn, O.DT_BF16, seed=11)
+            lg = to_device_logits(c["logits"], c["dtype"]).view(Bn, Kn, Vn)
+            tok, lp_d, u = (torch.from_numpy(c[k]).cuda() for k in ("tok", "lp_d", "u"))
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(20):
+                    ops.verify_accept(lg, tok, lp_d, u)
+                barrier.wait(timeout=60)                 # both threads have profiled their last step before either reads
+                got[name] = ops.stats()
+        except Exception as e:  # noqa: BLE001
+            errs.append((name, repr(e)))
+    ts = [threading.Thread(target=work, args=(n,)) for n in shapes]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
+    for name, (Bn, Kn, Vn) in shapes.items():
+        assert got[name]["algorithmic_bytes"] == Bn * Kn * Vn * 2 + 17 * Bn * Kn + 12 * Bn, (name, got[name])
+        assert got[name]["kernel_us"] > 0
+    assert ops.stats() == {}                             # this (main) thread profiled nothing

@@ -631,21 +631,21 @@ def test_a_withheld_hand_off_poisons_the_result_instead_of_folding_a_zero(K_, fo
     tok, lp_d, u = (torch.from_numpy(c[k]).cuda() for k in ("tok", "lp_d", "u"))
     ws = K_.VerifyWorkspace(B, 8, V)
     feat, packed, Cc = _fused_args(K_, B)
-    lib = K_._lib()
     cus = K_.device_cu_count()
     S = 1 if B * 8 >= cus else -(-cus // (B * 8))          # the launcher's split count (rows < CUs: ceil(CUs / rows))
     bad_b, bad_k = 3, 5
     row = bad_b * 8 + bad_k
-    try:
-        lib.asd_debug_verify_withhold(row * S + (S - 1))
-        ph = torch.ones((B, 3), dtype=torch.float64, device="cuda")
-        if form == "split":
-            v, s = K_.verify_accept(lg, tok, lp_d, u, ws), None
-        else:
-            v, s = K_.verify_accept_fused(lg, tok, lp_d, u, ws, feat, packed, 64, 32, stage_idx=0, L=3, p_hist=ph, Cc=Cc, lam=0.8)
-        torch.cuda.synchronize()
-    finally:
-        lib.asd_debug_verify_withhold(-1)
+    with K_.test_hooks() as lib:                            # the fault-injection switch exists in the TEST build of the library only
+        try:
+            lib.asd_debug_verify_withhold(row * S + (S - 1))
+            ph = torch.ones((B, 3), dtype=torch.float64, device="cuda")
+            if form == "split":
+                v, s = K_.verify_accept(lg, tok, lp_d, u, ws), None
+            else:
+                v, s = K_.verify_accept_fused(lg, tok, lp_d, u, ws, feat, packed, 64, 32, stage_idx=0, L=3, p_hist=ph, Cc=Cc, lam=0.8)
+            torch.cuda.synchronize()
+        finally:
+            lib.asd_debug_verify_withhold(-1)
     lp = v.lp_target.cpu().numpy()
     acc = v.accept.cpu().numpy()
     others = np.ones((B, 8), bool)

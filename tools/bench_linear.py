@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--tall-mode", type=int, default=None, help="asd_debug_linear_tall: 0 off, 1 for 256 < M <= 288, 2 also for 192 < M <= 256")
     ap.add_argument("--no-torch", action="store_true")
     a = ap.parse_args()
-    lib = K_._lib()
+    lib = K_.test_hooks().__enter__()          # the TEST build of the library for the whole program (asd_debug_* switches)
     lib.asd_debug_force_linear_slices(a.force_slices)
     if a.tall_mode is not None:
         lib.asd_debug_linear_tall(a.tall_mode)
@@ -71,7 +71,7 @@ def main():
                 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
                 t_asd = time_us(lambda i: K_.linear(x, W[i], workspace=ws, out=out), n_rot)
                 t_torch = float("nan") if a.no_torch else time_us(lambda i: F.linear(x, W[i]), n_rot)
-                r = {"model": name, "matrix": mname, "M": M, "N": N, "D": D, "slices": int(lib.asd_debug_linear_slices(M, N, D)),
+                r = {"model": name, "matrix": mname, "M": M, "N": N, "D": D, "slices": int(lib.asd_linear_slices(M, N, D)),
                      "asd_us": round(t_asd, 2), "torch_us": round(t_torch, 2), "asd_TBps": round(wbytes / t_asd / 1e6, 3),
                      "torch_TBps": round(wbytes / t_torch / 1e6, 3), "asd_TFLOPs": round(2.0 * M * N * D / t_asd / 1e6, 1)}
                 res.append(r)

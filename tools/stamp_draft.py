@@ -28,7 +28,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     lib_path = os.path.join(out, "libasd_draft_stamp.so")
     csrc = os.path.join(ROOT, "adaptive-speculative-decoding_amd", "csrc")
-    subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-DASD_STAMP",
+    subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-DASD_STAMP", "-DASD_TEST_HOOKS",
                            f"-I{ROOT}/include", f"-I{csrc}", os.path.join(csrc, "draft_sample.hip"), os.path.join(csrc, "api.hip"), "-o", lib_path])
     lib = C.CDLL(lib_path)
     lib.asd_debug_draft_groups(-1)       # the stamps live in k_draft_row, the one-workgroup-per-row streaming form (B > 128)

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None, help="comma-separated matrix names (qkv, o, gate_up, down, lm_head)")
     a = ap.parse_args()
-    lib = K_._lib()
+    lib = K_.test_hooks().__enter__()          # the TEST build of the library for the whole program (asd_debug_force_linear_slices)
     ws = K_.LinearWorkspace("cuda")
     s = SL.QWEN25_SHAPES[a.model]
     kv = s.kv_heads * s.head_dim
@@ -39,7 +39,7 @@ def main():
         for M in [int(v) for v in a.rows.split(",")]:
             x = torch.randn(M, D, device="cuda", dtype=torch.bfloat16)
             out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-            plan = int(lib.asd_debug_linear_slices(M, N, D))
+            plan = int(lib.asd_linear_slices(M, N, D))
             row = {"model": a.model, "matrix": mname, "M": M, "N": N, "D": D, "plan": plan, "us": {}}
             ws.buf = torch.empty(32 * M * N * 4 + 1024, dtype=torch.uint8, device="cuda")
             for k in [int(v) for v in a.slices.split(",")]:
