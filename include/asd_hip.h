@@ -245,7 +245,12 @@ int asd_linear_slices(int M, int N, int D);
  *   asd_decoder_forward  n_layers x (rmsnorm, qkv, rope + cache write, attention, o + residual, rmsnorm, gate | up, silu * up,
  *                      down + residual) on x [M][ld_x] in place -- nine launches per layer, all issued by this one call.
  * Entries of the caches past a sequence's committed length are rewritten before they are read (KV rollback = a length
- * update, asd_commit_step); the caches must hold finite values from the start (zero-fill them once). */
+ * update, asd_commit_step).  CONTRACT of the caches (X3 is plumbing around the path, third party in the reference):
+ *   - they must hold FINITE values from the start (zero-fill them once): asd_attn_ragged masks keys beyond pos by giving them
+ *     probability 0, but still feeds the whole 32-key tile through the MFMA, and 0 * NaN = NaN;
+ *   - positions are clamped into [0, t_max - 1] by BOTH kernels; slot t_max - 1 is therefore a TRASH slot (the padding
+ *     behind a ragged feed lands there, several rows may write it): size t_max at least one slot beyond the longest real
+ *     sequence (serving/hierarchy.py does) and never pass a negative position for a row whose result is used. */
 typedef struct asd_layer {
     const void* ln1_w;      /* [hidden] */
     const void* qkv_w;      /* [hidden + 2 * KVH * 128][hidden]: q | k | v projection rows */
