@@ -215,6 +215,47 @@ __global__ __launch_bounds__(64) void k_predictor_stop_w64x32(const float* a_lp,
     epi_finish(p, b, lane, lpv, n, want_stats, e, dvals, xs);
 }
 
+// Latency form for the 256 -> 128 -> 1 predictor (the reference's server: QualityPredictor(feature_dim=256), server.py:168) and
+// K <= 64: ONE workgroup of eight waves per sequence -- the first layer cut over the waves (predictor_device.hpp: epi2_partial),
+// wave 0 does the statistics and the rest.  The in-kernel epilogue of k_verify<..., EPI = 2> runs the same functions in the same
+// order: bit-identical scores.
+__global__ __launch_bounds__(64 * kEpi2Waves) void k_predictor_stop_w256x128(const FusedParams p) {
+    __shared__ float part[kEpi2Waves * kEpi2Hid];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int b = blockIdx.x;
+    const bool want_stats = p.lp && (p.stats_col >= 0 || p.stats);
+    const float xv = epi2_feature(p.feat + static_cast<int64_t>(b) * p.ldf, p.stats_col, wave, lane);
+    uint32_t raw_n = static_cast<uint32_t>(p.K), raw_lp = 0u;
+    Epi2Tail t{};
+    if (wave == 0) {
+        int vb = b;
+        asm volatile("" : "+v"(vb));
+        if (want_stats && p.n_valid) raw_n = reinterpret_cast<const uint32_t*>(p.n_valid)[vb];
+        if (want_stats && lane < p.K) raw_lp = reinterpret_cast<const uint32_t*>(p.lp)[static_cast<int64_t>(vb) * p.ld_lp + lane];
+        epi2_tail_prefetch(p.packed, p.stats_col, lane, t);
+    }
+    float h0, h1;
+    epi2_partial(p.packed, wave, lane, xv, h0, h1);
+    part[wave * kEpi2Hid + lane] = h0;
+    part[wave * kEpi2Hid + 64 + lane] = h1;
+    __syncthreads();
+    if (wave != 0) return;
+    asm volatile("" : "+v"(raw_n), "+v"(raw_lp));
+    int n = __builtin_amdgcn_readfirstlane(static_cast<int>(raw_n));
+    n = n < 0 ? 0 : (n > p.K ? p.K : n);
+    double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (want_stats) {
+        wave_logprob_stats_regs(__uint_as_float(raw_lp), n, lane, st);
+        if (p.stats && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
+        }
+    }
+    const float sc = epi2_score(part, lane, t, st, want_stats && p.stats_col >= 0);
+    if (lane == 0) decide_and_store(p, b, sc);
+}
+
 inline bool mlp_dims_ok(int in_dim, int hidden) {
     return in_dim >= 1 && hidden >= 1 && in_dim <= ASD_MAX_MLP_DIM && hidden <= ASD_MAX_MLP_DIM;
 }
@@ -309,6 +350,10 @@ ASD_EXPORT int asd_predictor_stop(const float* lp, int64_t ld_lp, const int32_t*
     if (in_dim == 64 && hidden == 32 && K <= 64 && B <= 8192) {
         hipLaunchKernelGGL(k_predictor_stop_w64x32, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), p.lp, p.ld_lp, p.feat,
                            p.ldf, p.packed, p.K, p);
+        return launch_status();
+    }
+    if (in_dim == kEpi2In && hidden == kEpi2Hid && K <= 64 && B <= 8192) {
+        hipLaunchKernelGGL(k_predictor_stop_w256x128, dim3(B), dim3(64 * kEpi2Waves), 0, static_cast<hipStream_t>(stream), p);
         return launch_status();
     }
     hipLaunchKernelGGL(k_predictor_stop, dim3(blocks), dim3(64 * kWavesPerBlock), lds, static_cast<hipStream_t>(stream), p);

@@ -565,4 +565,92 @@ __device__ __forceinline__ void epi_finish_lds(const FusedParams& p, int b, int 
     }
 }
 
+// ---- the 256 -> 128 -> 1 predictor (the reference's server instantiates `QualityPredictor(feature_dim=256)`,
+// src/serving/server.py:168; spec docs/guides/RESEARCH_PROTOCOL.md:315-364), latency forms: k_predictor_stop_w256x128 and the
+// in-kernel epilogue of k_verify<..., EPI = 2>.  33 025 weights (129 KiB) do not fit the LDS a streaming kernel can spare and one
+// wave would need ~1300 instructions for the first layer, so the layer is cut over the EIGHT waves of the (finisher's) workgroup
+// -- in the verify kernel they have finished streaming and would otherwise exit:
+//   wave w        columns [32 w, 32 w + 32) of the feature row (statistics columns zeroed: they come last, like the 64 x 32 form)
+//                 lane j: h0 = sum_i W1[j][c_i] x[c_i],  h1 = the same for hidden unit 64 + j   (FMA chains in column order;
+//                 the feature values travel lane -> SGPR by v_readlane, the weights are coalesced global loads, L2-resident)
+//                 -> part[w][j], part[w][64 + j] in LDS;  workgroup barrier
+//   wave 0        h = ((((((part[0] + part[1]) + part[2]) + ...) + part[7]);  the five statistics columns (phase B);
+//                 + b1; ReLU;  t = fma(W2[64 + j], h1, W2[j] h0);  z = wave_sum(t);  sigmoid(z + b2)  (epi_score's sigmoid)
+// CANONICAL ORDER of both latency forms (bit-identical scores); against the oracle the bar is 1e-5.
+constexpr int kEpi2In = 256, kEpi2Hid = 128, kEpi2Waves = 8, kEpi2Cols = kEpi2In / kEpi2Waves;
+// xv: lanes 0..31 hold the feature values of this wave's 32 columns (statistics columns zeroed); packed: GLOBAL
+__device__ __forceinline__ void epi2_partial(const float* packed, int w, int lane, float xv, float& h0, float& h1) {
+    h0 = 0.0f;
+    h1 = 0.0f;
+    const float* wp = packed + static_cast<int64_t>(w) * kEpi2Cols * kEpi2Hid + lane;
+#pragma unroll 8
+    for (int i = 0; i < kEpi2Cols; ++i) {
+        const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xv), i));
+        h0 = fmaf(wp[i * kEpi2Hid], x, h0);
+        h1 = fmaf(wp[i * kEpi2Hid + 64], x, h1);
+    }
+}
+// this wave's slice of the feature row, one value per lane (lanes < 32), statistics columns zeroed
+__device__ __forceinline__ float epi2_feature(const float* feat_row, int stats_col, int w, int lane) {
+    const int c = w * kEpi2Cols + (lane & 31);
+    const float x = feat_row[c];
+    const int si = c - stats_col;
+    return (stats_col >= 0 && si >= 0 && si < ASD_NUM_LP_STATS) ? 0.0f : x;
+}
+struct Epi2Tail {          // what wave 0 reads from global memory for the steps behind the statistics (issued early)
+    float wd0[ASD_NUM_LP_STATS], wd1[ASD_NUM_LP_STATS], b1a, b1b, w2a, w2b, b2;
+};
+__device__ __forceinline__ void epi2_tail_prefetch(const float* packed, int stats_col, int lane, Epi2Tail& t) {
+    const int col = stats_col >= 0 ? stats_col : 0;
+#pragma unroll
+    for (int d = 0; d < ASD_NUM_LP_STATS; ++d) {
+        t.wd0[d] = packed[(col + d) * kEpi2Hid + lane];
+        t.wd1[d] = packed[(col + d) * kEpi2Hid + 64 + lane];
+    }
+    const float* b1 = packed + kEpi2In * kEpi2Hid;
+    t.b1a = b1[lane]; t.b1b = b1[64 + lane];
+    t.w2a = b1[kEpi2Hid + lane]; t.w2b = b1[kEpi2Hid + 64 + lane];
+    t.b2 = b1[2 * kEpi2Hid];
+}
+// part: [8][128] floats of LDS (all eight partials written, workgroup barrier passed); st: the statistics (uniform)
+__device__ __forceinline__ float epi2_score(const float* part, int lane, const Epi2Tail& t, const double (&st)[5], bool overlay) {
+    float h0 = part[lane], h1 = part[64 + lane];
+#pragma unroll
+    for (int w = 1; w < kEpi2Waves; ++w) {
+        h0 = h0 + part[w * kEpi2Hid + lane];
+        h1 = h1 + part[w * kEpi2Hid + 64 + lane];
+    }
+    if (overlay) {
+#pragma unroll
+        for (int d = 0; d < ASD_NUM_LP_STATS; ++d) {
+            const float sd = static_cast<float>(st[d]);
+            h0 = fmaf(t.wd0[d], sd, h0);
+            h1 = fmaf(t.wd1[d], sd, h1);
+        }
+    }
+    h0 = fmaxf(h0 + t.b1a, 0.0f);
+    h1 = fmaxf(h1 + t.b1b, 0.0f);
+    const float z = wave_sum(fmaf(t.w2b, h1, t.w2a * h0));
+    const float e = __builtin_amdgcn_exp2f(-(z + t.b2) * kLog2e);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+// the in-kernel finish for the 256 -> 128 -> 1 form (wave 0 of the finisher's workgroup, behind the partials' barrier)
+__device__ __forceinline__ void epi2_finish_lds(const FusedParams& p, int b, int lane, float lpv, int n, bool want_stats,
+                                                const double* decide_lds, const float* part, const Epi2Tail& t) {
+    double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (want_stats) {
+        wave_logprob_stats_row16(lpv, n, lane, st);      // n <= kEpiInKernelMaxK
+        if (p.stats && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p.stats[5 * static_cast<int64_t>(b) + i] = st[i];
+        }
+    }
+    const float sc = epi2_score(part, lane, t, st, want_stats && p.stats_col >= 0);
+    if (lane == 0) {
+        DecidePrefetch d;
+        epi_decide_from_lds(decide_lds, d);
+        decide_and_store_small(p, b, sc, d);
+    }
+}
+
 }  // namespace asd

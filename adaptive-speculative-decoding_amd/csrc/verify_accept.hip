@@ -207,7 +207,10 @@ __device__ __forceinline__ float row_entropy_nats(float m2, float s, float t, fl
 // any s_load of the kernarg segment (the by-value struct is fetched meanwhile and first used behind those loads).
 // STATS: additionally carries t = sum e * x through the stream (one more FMA per element, a third slot value per tile)
 // for the row entropy (asd_verify_accept_stats); its own instantiation so that the plain kernel pays nothing.
-template <int DT, int THREADS, int UNROLL, bool NT, bool FUSED, bool STATS = false>
+// EPI (FUSED only): 1 = the reference's 64 -> 32 -> 1 predictor (weights in LDS by DMA, one wave), 2 = the 256 -> 128 -> 1 predictor
+// of the reference's server (first layer cut over the eight waves of the finisher's workgroup: predictor_device.hpp, epi2_*; one
+// workgroup per row only -- the launcher sends split-row launches down the two-launch route).
+template <int DT, int THREADS, int UNROLL, bool NT, bool FUSED, bool STATS = false, int EPI = 1>
 __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const int32_t* a_tok, int64_t a_ld_row, int a_V,
                                                     int a_K, int a_S, float a_scale2, int a_own, const VerifyParams p) {
     using E = Elem<DT>;
@@ -215,7 +218,9 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     __shared__ uint32_t next_tile;
     __shared__ __attribute__((aligned(16))) uint64_t stage[kMaxStage];   // tile slots while streaming, then scratch of the finisher
     __shared__ float stage_t[STATS ? kMaxStage : 1];                      // STATS: the tiles' third value
-    __shared__ __attribute__((aligned(16))) float wlds[FUSED ? 64 * 32 + 68 : 4];   // FUSED: the predictor's packed weights (LDS-DMA)
+    static_assert(EPI == 1 || (EPI == 2 && THREADS == 64 * kEpi2Waves), "the 256 x 128 epilogue is cut over eight waves");
+    // FUSED: the predictor's packed weights (EPI 1, LDS-DMA) / the eight waves' partial first-layer sums (EPI 2)
+    __shared__ __attribute__((aligned(16))) float wlds[FUSED ? (EPI == 2 ? kEpi2Waves * kEpi2Hid : 64 * 32 + 68) : 4];
     __shared__ __attribute__((aligned(16))) double dlds[FUSED ? kEpiDecideLds : 1];  // FUSED: the decision inputs (LDS-DMA)
 
     ASD_STAMP_AT(0);
@@ -354,7 +359,29 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         g_asd_stamps[static_cast<size_t>(gridDim.x * gridDim.y) * 16 + static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
     FusedParams ep;   // FUSED: the epilogue's parameters (wave 0 only; fetched below)
-    if (__builtin_amdgcn_readfirstlane(wave) == 0) {   // (wave-uniform for the compiler too: the parameters below live in SGPRs)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // EPI 2: every wave of the finisher's workgroup computes a slice of the predictor's first layer behind the barrier below; what
+    // it needs of the parameters (feature row, packed weights, statistics column) it fetches itself, here, behind its stream
+    const bool fin_wg = FUSED && fused && k == a_K - 1 && (own_row || split == S - 1);
+    float xv2 = 0.0f;
+    const float* packed2 = nullptr;
+    int col2 = -1;
+    if constexpr (FUSED && EPI == 2) {
+        if (fin_wg) {
+            typedef const __attribute__((address_space(4))) char* ka_ptr2;
+            typedef const __attribute__((address_space(4))) FusedParams* ka_epi_ptr2;
+            ka_ptr2 ka2 = (ka_ptr2)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka2));
+            const ka_epi_ptr2 kp2 = (ka_epi_ptr2)(ka2 + kKernargParamsOffset + __builtin_offsetof(VerifyParams, epi));
+            const float* feat2 = pin_global_ptr(kp2->feat);
+            int64_t ldf2 = kp2->ldf;
+            col2 = kp2->stats_col;
+            packed2 = pin_global_ptr(kp2->packed);
+            ASD_PIN(ldf2); ASD_PIN(col2);
+            xv2 = epi2_feature(feat2 + static_cast<int64_t>(b) * ldf2, col2, wave_u, lane);
+        }
+    }
+    if (wave_u == 0) {   // (wave-uniform for the compiler too: the parameters below live in SGPRs)
         // the small loads issued ahead of the loop are consumed here: head / tail elements -> slot n_tiles,
         // the drafted token's logit and log(u) for lane 0
         // pin the first use of the loaded values HERE: without it the compiler hoists the (cheap, speculatable)
@@ -390,7 +417,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
 #if defined(ASD_LAB) && ASD_LAB == 5   // lab: no weight DMA, no feature load
             if (false) {
 #else
-            if (fused && k == a_K - 1 && (own_row || split == S - 1)) {
+            if (EPI == 1 && fin_wg) {
 #endif
                 typedef __attribute__((address_space(3))) void lds_void;
                 typedef const __attribute__((address_space(1))) void glb_void;
@@ -432,7 +459,18 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     }
     // tile slots -> slice: wave 0 folds slots lane, lane+64, ... in order, then across lanes
     __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(wave) != 0) return;
+    if (wave_u != 0) {
+        if constexpr (FUSED && EPI == 2) {
+            if (fin_wg) {   // this wave's 32 columns of the predictor's first layer -> LDS; wave 0 joins the barrier behind its own slice
+                float h0, h1;
+                epi2_partial(packed2, wave_u, lane, xv2, h0, h1);
+                wlds[wave_u * kEpi2Hid + lane] = h0;
+                wlds[wave_u * kEpi2Hid + 64 + lane] = h1;
+                __syncthreads();
+            }
+        }
+        return;
+    }
     float m2 = kSentinel, s = 0.0f, tsum = 0.0f;
     for (uint32_t t = static_cast<uint32_t>(lane); t <= n_tiles; t += 64) {
         const uint64_t g = stage[t];
@@ -478,18 +516,32 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
                 return;
             }
             ASD_STAMP_AT(4);
-            // the weight DMA and the feature row were issued behind the stream, a barrier + slot fold + finish_row ago: landed
-            // (nothing younger is outstanding yet, so this wait names exactly them)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_feat) :: "memory");
             uint64_t sv = __shfl(mine, 0, 64);              // the finisher's own row (lane K - 1 keeps it)
-            if (lane < p.K - 1) sv = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // first probe: issued ...
-            // ... and phase A of the predictor's first layer (everything but the five statistics columns) runs under it
-            EpiPhaseA pa;
-            epi_phase_a_lds(ep, lane, __uint_as_float(raw_feat), wlds, reinterpret_cast<float*>(stage + 192), pa);
-            {
+            EpiPhaseA pa{};
+            Epi2Tail tail2{};
+            if constexpr (EPI == 1) {
+                // the weight DMA and the feature row were issued behind the stream, a barrier + slot fold + finish_row ago: landed
+                // (nothing younger is outstanding yet, so this wait names exactly them)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_feat) :: "memory");
+                if (lane < p.K - 1) sv = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // first probe: issued ...
+                // ... and phase A of the predictor's first layer (everything but the five statistics columns) runs under it
+                epi_phase_a_lds(ep, lane, __uint_as_float(raw_feat), wlds, reinterpret_cast<float*>(stage + 192), pa);
                 uint32_t sv_lo = static_cast<uint32_t>(sv), sv_hi = static_cast<uint32_t>(sv >> 32);
                 asm volatile("" : "+v"(pa.h), "+v"(pa.wd[0]), "+v"(pa.wd[1]), "+v"(pa.wd[2]), "+v"(pa.wd[3]), "+v"(pa.wd[4]), "+v"(pa.b1), "+v"(pa.w2),
                              "+v"(pa.b2), "+v"(sv_lo), "+v"(sv_hi));   // the probe's first use is HERE, behind phase A
+                sv = (static_cast<uint64_t>(sv_hi) << 32) | sv_lo;
+            } else {
+                // EPI 2: the first probe, then wave 0's own 32 columns of the first layer and the weights the tail needs -- the
+                // other seven waves have been computing theirs since the barrier; all eight meet at the barrier below
+                if (lane < p.K - 1) sv = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                epi2_tail_prefetch(packed2, col2, lane, tail2);
+                float h0, h1;
+                epi2_partial(packed2, 0, lane, xv2, h0, h1);
+                wlds[lane] = h0;
+                wlds[64 + lane] = h1;
+                __syncthreads();
+                uint32_t sv_lo = static_cast<uint32_t>(sv), sv_hi = static_cast<uint32_t>(sv >> 32);
+                asm volatile("" : "+v"(sv_lo), "+v"(sv_hi));
                 sv = (static_cast<uint64_t>(sv_hi) << 32) | sv_lo;
             }
             epi_decide_dma(ep, b, lane, dlds);           // the decision inputs (p_hist row, stage costs, theta) -> LDS while the slots are polled
@@ -527,7 +579,10 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             if (lane == 0 && ep.score) ep.score[b] = pa.h + pa.wd[0] + pa.b1 + pa.w2 + pa.b2 + __uint_as_float(static_cast<uint32_t>(sv));
             return;
 #endif
-            epi_finish_lds(ep, b, lane, __uint_as_float(static_cast<uint32_t>(sv)), p.K, ep.stats_col >= 0 || ep.stats != nullptr, dlds, pa);
+            if constexpr (EPI == 1)
+                epi_finish_lds(ep, b, lane, __uint_as_float(static_cast<uint32_t>(sv)), p.K, ep.stats_col >= 0 || ep.stats != nullptr, dlds, pa);
+            else
+                epi2_finish_lds(ep, b, lane, __uint_as_float(static_cast<uint32_t>(sv)), p.K, ep.stats_col >= 0 || ep.stats != nullptr, dlds, wlds, tail2);
             ASD_STAMP_AT(8);
             return;
         }
@@ -591,8 +646,8 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         xv0 = __hip_atomic_load(xslots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane < KS) gv0 = __hip_atomic_load(region + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    EpiPhaseA pa;
-    if (FUSED) {
+    EpiPhaseA pa{};
+    if constexpr (FUSED && EPI == 1) {      // (EPI 2 is launched with one workgroup per row only)
         if (fused) {
             epi_phase_a_lds(ep, lane, __uint_as_float(raw_feat), wlds, reinterpret_cast<float*>(stage + 192), pa);
             uint32_t a0 = static_cast<uint32_t>(xv0), a1 = static_cast<uint32_t>(xv0 >> 32), g0 = static_cast<uint32_t>(gv0), g1 = static_cast<uint32_t>(gv0 >> 32);
@@ -650,7 +705,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         if (p.row_max_lp) p.row_max_lp[frow] = row_max_logprob(fs);
     }
     finish_sequence(flag, lane, p.K, b, p.n_acc, p.bits);
-    if (FUSED) {
+    if constexpr (FUSED && EPI == 1) {
         if (!fused) return;
         // the finisher's lanes hold all K lp_t: the predictor / stop epilogue runs right here (no hand-off at all)
         if (__ballot(lost) != 0ull) {
@@ -821,6 +876,19 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
         const dim3 gd(static_cast<uint32_t>(grid / p.S), static_cast<uint32_t>(p.S));
         const bool wide = (g.threads == 512 && g.unroll == 3);
         if (!wide && !(g.threads == 512 && g.unroll == 2)) return ASD_ERR_UNSUPPORTED;
+        if (p.fused == 2) {   // the 256 -> 128 -> 1 epilogue: one workgroup per row, 512 lanes x 3-KiB tiles only
+            if (g.splits != 1 || !wide || !own_row_of(p)) return ASD_ERR_UNSUPPORTED;
+#define ASD_LAUNCH_FUSED2(DT)                                                                                     \
+    hipLaunchKernelGGL((k_verify<DT, 512, 3, true, true, false, 2>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row, p.V, \
+                       p.K, p.S, p.scale2, own_row_of(p), p)
+            switch (dtype) {
+                case ASD_DTYPE_BF16: ASD_LAUNCH_FUSED2(ASD_DTYPE_BF16); break;
+                case ASD_DTYPE_F16: ASD_LAUNCH_FUSED2(ASD_DTYPE_F16); break;
+                default: ASD_LAUNCH_FUSED2(ASD_DTYPE_F32); break;
+            }
+#undef ASD_LAUNCH_FUSED2
+            return launch_status();
+        }
 #define ASD_LAUNCH_FUSED(DT)                                                                                      \
     do {                                                                                                          \
         if (wide) hipLaunchKernelGGL((k_verify<DT, 512, 3, true, true>), gd, dim3(512), 0, st, p.logits, p.tok, p.ld_row, \
@@ -955,7 +1023,12 @@ ASD_EXPORT int asd_verify_accept_fused_ex(const void* logits, int dtype, int64_t
     // same results from two launches
     const bool geometry_ok = (g.threads == 0 || g.threads == 512) && (g.unroll == 0 || g.unroll == 2 || g.unroll == 3);
     const bool in_kernel = in_dim == 64 && hidden == 32 && geometry_ok && L <= kDecidePrefetch && K <= kEpiInKernelMaxK;
-    if (!in_kernel) {
+    // ... and, with one workgroup per row (rows >= CUs, nothing forced), the 256 -> 128 -> 1 predictor of the reference's server
+    // (src/serving/server.py:168): its first layer is cut over the eight waves of the finisher's workgroup
+    const bool default_geometry = !opt || (opt->splits <= 0 && opt->threads <= 0 && opt->unroll <= 0);
+    const bool in_kernel2 = in_dim == kEpi2In && hidden == kEpi2Hid && default_geometry && L <= kDecidePrefetch && K <= kEpiInKernelMaxK &&
+                            static_cast<int64_t>(B) * K >= current_device_cus();
+    if (!in_kernel && !in_kernel2) {
         const int rc = asd_verify_accept_ex(logits, dtype, ld_row, tok, lp_draft, u, B, K, V, lp_target, accept, n_acc,
                                             accept_bits, workspace, workspace_bytes, opt, stream);
         if (rc != ASD_OK) return rc;
@@ -966,7 +1039,7 @@ ASD_EXPORT int asd_verify_accept_fused_ex(const void* logits, int dtype, int64_t
     p.logits = logits; p.ld_row = ld_row; p.tok = tok; p.lp_d = lp_draft; p.u = u;
     p.B = B; p.K = K; p.V = V; p.v_offset = 0;
     p.lp_t = lp_target; p.accept = accept; p.n_acc = n_acc; p.bits = accept_bits;
-    p.msg = nullptr; p.mode = 0; p.fused = 1;
+    p.msg = nullptr; p.mode = 0; p.fused = in_kernel2 ? 2 : 1;
     FusedParams& e = p.epi;
     e.lp = nullptr; e.ld_lp = K; e.n_valid = nullptr; e.K = K;
     e.feat = feat; e.ldf = ldf; e.stats_col = stats_col;

@@ -453,9 +453,11 @@ int asd_draft_sample(const void* logits, int64_t ld, int dtype, const float* r /
  * positions valid).  ONE launch per tier step instead of two, at every batch size: with one workgroup
  * per row (B*K >= CUs) every row hands its lp_t to the sequence's finisher through a self-tagging
  * workspace slot; with split rows (B*K < CUs, e.g. B = 8) the finisher wave already holds all K lp_t.
- * The in-kernel form covers the reference's 64->32->1 predictor (src/minimal_adaptive_decoder.py:38-49);
- * any other predictor shape is served by the same call as two launches with identical results
- * (bit-identical: tests/test_gpu_predictor.py).  Parameters: those of asd_verify_accept followed by those
+ * The in-kernel form covers the reference's 64->32->1 predictor (src/minimal_adaptive_decoder.py:38-49) and -- with one
+ * workgroup per row -- the 256->128->1 predictor its server instantiates (QualityPredictor(feature_dim=256),
+ * src/serving/server.py:168; docs/guides/RESEARCH_PROTOCOL.md:315-364), for hierarchies of <= 4 tiers and draft lengths
+ * <= 16; any other predictor shape, depth, draft length or forced geometry is served by the same call as two launches with
+ * identical results (bit-identical: tests/test_gpu_predictor.py).  Parameters: those of asd_verify_accept followed by those
  * of asd_predictor_stop (without lp / n_valid / K / B); _ex adds asd_verify_options (inv_temperature:
  * the tiers verify at T = 0.7, pipeline.py:94).  Replaces the per-stage sequence
  * predictor.predict -> bayesian_adjustment -> optimal_stopping_rule of src/serving/pipeline.py:225-261. */

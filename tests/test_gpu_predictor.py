@@ -188,3 +188,91 @@ def test_in_kernel_epilogue_equals_two_launches(golden, K_, B, K, V, T):
         assert_verify_matches(got, case["ref"])
     stats = O.logprob_stats(got["lp_t"], None, K)
     assert s2.stats.cpu().numpy().tobytes() == stats.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the 256 -> 128 -> 1 predictor of the reference's server (QualityPredictor(feature_dim=256), src/serving/server.py:168;
+# docs/guides/RESEARCH_PROTOCOL.md:315-364) -- a doc-level spec, no reference arithmetic to pin: parity vs the oracle's generic MLP
+def _w256(seed=3):
+    rng = np.random.default_rng(seed)
+    w1 = (rng.standard_normal((128, 256)) / 16).astype(np.float32)
+    b1 = (rng.standard_normal(128) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((1, 128)) / 8).astype(np.float32)
+    b2 = np.array([0.05], np.float32)
+    return w1, b1, w2, b2
+
+
+@pytest.mark.parametrize("B,K", [(1, 8), (33, 8), (256, 16), (40, 40), (8, 3)])
+def test_predictor_stop_256x128_latency_form_matches_the_oracle(K_, B, K):
+    """asd_predictor_stop with in_dim 256 / hidden 128: one workgroup of eight waves per sequence (k_predictor_stop_w256x128)."""
+    import torch
+    w1, b1, w2, b2 = _w256()
+    packed = K_.pack_mlp_weights(w1, b1, w2, b2)
+    rng = np.random.default_rng(B * 7 + K)
+    feat = (rng.standard_normal((B, 256)) * 0.3).astype(np.float32)
+    lp = (-np.abs(rng.standard_normal((B, K))) * 2).astype(np.float32)
+    nv = rng.integers(0, K + 1, B).astype(np.int32)
+    Cc = np.array([1.0, 4.5, 10.0])
+    for col in (5, 30, 251, -1):
+        p_hist = rng.uniform(0.2, 1.0, (B, 3))
+        p_hist[:, 2] = 1.0
+        ph = _cuda(p_hist, np.float64)
+        r = K_.predictor_stop(_cuda(feat, np.float32), packed, 256, 128, stage_idx=1, L=3, lp=_cuda(lp, np.float32),
+                              n_valid=_cuda(nv, np.int32), stats_col=col, risk_adjustment=True, n_obs=150, alpha=1.0, beta=2.0,
+                              p_hist=ph, Cc=_cuda(Cc, np.float64), lam=0.7, want_stats=True)
+        torch.cuda.synchronize()
+        stats = O.logprob_stats(lp, nv, K)
+        assert r.stats.cpu().numpy().tobytes() == stats.tobytes()
+        x = feat.copy()
+        if col >= 0:
+            x[:, col:col + 5] = stats.astype(np.float32)
+        score = O.mlp_predict(x, w1, b1, w2[0], b2)
+        got = r.score.cpu().numpy()
+        np.testing.assert_allclose(got, score, rtol=0, atol=SCORE_ATOL)
+        want_hist = p_hist.copy()
+        want_hist[:, 1] = O.bayes_adjust(got.astype(np.float64), 150, 1.0, 2.0)
+        assert ph.cpu().numpy().tobytes() == want_hist.tobytes()
+        ks, _ = O.optimal_stopping(want_hist, Cc, 0.7)
+        assert np.array_equal(r.k_star.cpu().numpy(), ks)
+
+
+@pytest.mark.parametrize("B,K,V,T", [(32, 8, 30000, 1.0), (64, 4, 20000, 0.7), (16, 16, 9000, 1.0), (32, 8, 152064, 0.7),
+                                     (8, 8, 30000, 1.0), (40, 32, 5000, 1.0)])
+def test_in_kernel_epilogue_256x128_equals_two_launches(K_, B, K, V, T):
+    """asd_verify_accept_fused_ex with the 256 -> 128 -> 1 predictor == asd_verify_accept_ex + asd_predictor_stop, bit for bit:
+    in-kernel (k_verify<..., EPI = 2>: the first layer cut over the eight waves of the finisher's workgroup) with one workgroup per
+    row and K <= 16; split rows (B * K < CUs) and longer drafts take the two-launch route inside the same entry point."""
+    import torch
+    from tests.helpers import make_verify_case, to_device_logits
+    w1, b1, w2, b2 = _w256()
+    packed = K_.pack_mlp_weights(w1, b1, w2, b2)
+    case = make_verify_case(B, K, V, O.DT_BF16, seed=B + K)
+    lg = to_device_logits(case["logits"], case["dtype"]).view(B, K, V)
+    tok, lp_d, u = (torch.from_numpy(case[k]).cuda() for k in ("tok", "lp_d", "u"))
+    rng = np.random.default_rng(9)
+    feat_np = (rng.standard_normal((B, 256)) * 0.3).astype(np.float32)
+    feat = torch.from_numpy(feat_np).cuda()
+    Cc = torch.tensor([1.0, 4.5, 10.0], dtype=torch.float64, device="cuda")
+    theta = torch.tensor([0.6, 0.4, 0.0], dtype=torch.float64, device="cuda")
+    ws = K_.VerifyWorkspace(B, K, V)
+    inv_t = float(np.float32(1.0 / T))
+    for rep in range(3):
+        ph1 = torch.ones((B, 3), dtype=torch.float64, device="cuda")
+        ph2 = ph1.clone()
+        v1 = K_.verify_accept(lg, tok, lp_d, u, ws, inv_temperature=inv_t)
+        s1 = K_.predictor_stop(feat, packed, 256, 128, stage_idx=0, L=3, lp=v1.lp_target, stats_col=5, risk_adjustment=True,
+                               n_obs=120, alpha=1.0, beta=1.5, p_hist=ph1, Cc=Cc, lam=0.8, theta=theta, want_stats=True)
+        v2, s2 = K_.verify_accept_fused(lg, tok, lp_d, u, ws, feat, packed, 256, 128, stage_idx=0, L=3, stats_col=5,
+                                        risk_adjustment=True, n_obs=120, alpha=1.0, beta=1.5, p_hist=ph2, Cc=Cc, lam=0.8,
+                                        theta=theta, want_stats=True, inv_temperature=inv_t)
+        torch.cuda.synchronize()
+        assert int(ws.buf.count_nonzero()) == 0
+        for a, b in ((v1.lp_target, v2.lp_target), (v1.accept, v2.accept), (v1.n_acc, v2.n_acc), (v1.accept_bits, v2.accept_bits),
+                     (s1.stats, s2.stats), (s1.score, s2.score), (s1.k_star, s2.k_star), (s1.stop, s2.stop),
+                     (s1.thr_stop, s2.thr_stop), (ph1, ph2)):
+            assert torch.equal(a, b)
+    stats = O.logprob_stats(v2.lp_target.cpu().numpy(), None, K)
+    assert s2.stats.cpu().numpy().tobytes() == stats.tobytes()
+    x = feat_np.copy()
+    x[:, 5:10] = stats.astype(np.float32)
+    np.testing.assert_allclose(s2.score.cpu().numpy(), O.mlp_predict(x, w1, b1, w2[0], b2), rtol=0, atol=SCORE_ATOL)

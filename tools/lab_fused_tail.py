@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--reps", type=int, default=300)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "lab_fused_tail.json"))
+    ap.add_argument("--also-256x128", action="store_true", help="time the first variant's one-launch step with the 256 -> 128 -> 1 predictor too")
     ap.add_argument("--extra-libs", default="", help="name=path,... : prebuilt libraries (e.g. an older commit's build) timed in the same process")
     a = ap.parse_args()
     from asd_amd import kernels as K
@@ -79,6 +80,14 @@ def main():
         elif n == 4 or n >= 20:
             fns[f"plain/{n}"] = ("plain", pl)
 
+    big = None
+    if a.also_256x128:
+        rngb = np.random.default_rng(3)
+        pk = K.pack_mlp_weights((rngb.standard_normal((128, 256)) / 16).astype(np.float32), np.zeros(128, np.float32),
+                                (rngb.standard_normal((1, 128)) / 8).astype(np.float32), np.zeros(1, np.float32), device=dev)
+        fb = torch.from_numpy((rngb.standard_normal((B, 256)) * 0.3).astype(np.float32)).to(dev)
+        big = (pk, fb)
+        fns["fused 256x128"] = ("fused256", fns[f"fused/{variants[0]}"][1])
     for item in [x for x in a.extra_libs.split(",") if x]:
         name, path = item.split("=")
         lib = C.CDLL(path if os.path.isabs(path) else os.path.join(ROOT, path))
@@ -96,6 +105,11 @@ def main():
             return fn(bj["logits"].data_ptr(), 1, V, bj["tok"].data_ptr(), bj["lp_d"].data_ptr(), bj["u"].data_ptr(), B, Kk, V,
                       o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(),
                       ws.bytes, None, st)
+        if kind == "fused256":
+            return fn(bj["logits"].data_ptr(), 1, V, bj["tok"].data_ptr(), bj["lp_d"].data_ptr(), bj["u"].data_ptr(), B, Kk, V,
+                      o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes,
+                      big[1].data_ptr(), 256, 5, big[0].data_ptr(), 256, 128, 1, 100, 1.0, 1.0, ph.data_ptr(), Cc.data_ptr(), 1.0, N_STAGES, 0, 0,
+                      None, score.data_ptr(), ks.data_ptr(), stp.data_ptr(), None, None, None, st)
         return fn(bj["logits"].data_ptr(), 1, V, bj["tok"].data_ptr(), bj["lp_d"].data_ptr(), bj["u"].data_ptr(), B, Kk, V,
                   o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws.buf.data_ptr(), ws.bytes,
                   feat.data_ptr(), 64, 5, packed.data_ptr(), 64, 32, 1, 100, 1.0, 1.0, ph.data_ptr(), Cc.data_ptr(), 1.0, N_STAGES, 0, 0,
@@ -131,6 +145,8 @@ def main():
         assert launch(kind, fn, 0) == 0
         torch.cuda.synchronize()
         got = {"n_acc": o.n_acc.cpu().numpy().copy(), "accept": o.accept.cpu().numpy().copy(), "lp_t": o.lp_target.cpu().numpy().copy()}
+        if kind == "fused256":
+            continue
         if kind == "fused":
             got["score"] = score.cpu().numpy().copy()
             got["k_star"] = ks.cpu().numpy().copy()
