@@ -358,6 +358,10 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     if (lane == 0 && g_asd_stamps)   // per-wave stream end, after the per-workgroup records
         g_asd_stamps[static_cast<size_t>(gridDim.x * gridDim.y) * 16 + static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
+#if defined(ASD_LAB) && ASD_LAB == 8     // lab: the kernel ends behind the stream (no barrier, no fold, no tail): ramp + stream + per-tile math alone
+    if (lane == 0 && stage[0] == 0x1234567812345678ull) p.lp_t[row] = 0.0f;
+    return;
+#endif
     FusedParams ep;   // FUSED: the epilogue's parameters (wave 0 only; fetched below)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // EPI 2: every wave of the finisher's workgroup computes a slice of the predictor's first layer behind the barrier below; what
@@ -599,6 +603,10 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
             uint64_t* word = reinterpret_cast<uint64_t*>(line + 2);
             const uint64_t mine = (1ull << 32) | (static_cast<uint64_t>(flag ? 1u : 0u) << k);
             ASD_STAMP_AT(4);
+#if defined(ASD_LAB) && ASD_LAB == 9     // lab: no ballot atomic (what the tail's one memory round trip costs)
+            if (mine == 0x1234ull) p.n_acc[b] = 0;
+            return;
+#endif
             const uint64_t old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (static_cast<uint32_t>(old >> 32) == static_cast<uint32_t>(p.K - 1)) {
                 const uint32_t mask = static_cast<uint32_t>(old | mine);
