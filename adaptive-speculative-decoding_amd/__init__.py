@@ -17,4 +17,4 @@ raises if it (or a GPU) is missing.  There is no CPU fallback.
 from ._binding import AsdError, LIB_PATH, load_library  # noqa: F401
 from .backend import HipBackend, get_backend, set_backend  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"
