@@ -912,36 +912,112 @@ def main_dry(args):
         # the same sub-record keys (values null), one collective standing in for the exchanges
         plan = multi_gpu_plan(world)
         state = {"out": out, "phase": "loop"}
-        wd = _start_watchdog(args.multi_gpu_timeout, rank, state)
+        wd = _PhaseGuard(args.multi_gpu_timeout, rank, world, state, _job_store(dist))
         if args.dry_stall_rank == rank:
             time.sleep(3600)                  # test hook: a rank that hangs in the data path (the others block in the collective)
-        dist.all_reduce(torch.zeros(1))
+        rec = dict({k: None for k in LOOP_KEYS}, kind=plan["kind"], placement=plan["placement"], rccl_ranks=world,
+                   backend="none (dry run)")
+        try:
+            if args.dry_raise_rank in (rank, world):      # test hook: this rank's (`world`: every rank's) sub-record raises
+                raise RuntimeError("dry-run failure injected")
+            dist.all_reduce(torch.zeros(1))
+        except Exception as e:  # noqa: BLE001
+            rec = {"kind": plan["kind"], "error": f"{type(e).__name__}: {e}"}
+            wd.failed(rec["error"])
         wd.cancel()
         if out is not None:
             out["sharded_verify"] = {"ranks": world, "backend": "none (dry run)"}
-            out["loop"] = dict({k: None for k in LOOP_KEYS}, kind=plan["kind"], placement=plan["placement"], rccl_ranks=world,
-                               backend="none (dry run)")
+            out["loop"] = rec
     if rank == 0:
         _emit(out)
     if world > 1:
         dist.destroy_process_group()
 
 
-def _start_watchdog(seconds, rank, state):
-    """The data-path phase of a multi-GPU run is bounded: if a collective hangs, rank 0 prints the headline -- measured before,
-    over gloo -- with the error recorded in the sub-record that was running, and EVERY rank leaves with a non-zero code: a
-    process that touched the GPU and then hung is a failed run whatever it printed (and must not linger on the device)."""
-    import threading
+class _PhaseGuard:
+    """The data-path phase of a multi-GPU run is bounded and a failure on ONE rank is not left to the time bound.
 
-    def bail():
-        if rank == 0 and state.get("out") is not None:
-            state["out"][state.get("phase", "loop")] = {"error": f"timed out after {seconds:.0f} s"}
-            _emit(state["out"])
+    * Time bound: if a collective hangs, rank 0 prints the headline -- measured before, over gloo -- with the error recorded in the
+      sub-record that was running, and EVERY rank leaves with a non-zero code: a process that touched the GPU and then hung is a
+      failed run whatever it printed (and must not linger on the device).
+    * A rank whose sub-record RAISED reports it through the job's rendezvous store (`failed`).  If every rank raised (a symmetric
+      failure: nobody is blocked) the job goes on and the error is recorded in the sub-record, exit code 0.  If only some did, the
+      others sit in an exchange that will never complete: every rank's guard sees the report within a second, rank 0 prints the
+      headline with that rank's error and every rank leaves non-zero -- seconds, not the time bound."""
+
+    GRACE_S = 5.0
+
+    def __init__(self, seconds, rank, world, state, store=None):
+        import threading
+        self.seconds, self.rank, self.world, self.state, self.store = seconds, rank, world, state, store
+        self._stop = threading.Event()
+        # the time bound is a timer of its own: it must fire even while the report poller waits on the store
+        self._timer = threading.Timer(seconds, lambda: self._bail(f"timed out after {self.seconds:.0f} s"))
+        self._timer.daemon = True
+        self._timer.start()
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _key(self):
+        return f"asd_bench_failed/{self.state.get('phase', 'loop')}"
+
+    def _count(self):
+        if self.store is None:
+            return 0
+        try:
+            return int(self.store.add(self._key() + "/n", 0))
+        except Exception:  # noqa: BLE001  (the store lives on rank 0: gone when rank 0 is gone -- the time bound remains)
+            return 0
+
+    def _bail(self, why):
+        out, phase = self.state.get("out"), self.state.get("phase", "loop")
+        if self.rank == 0 and out is not None:
+            out[phase] = {"error": why}
+            _emit(out)
         os._exit(3)
-    t = threading.Timer(seconds, bail)
-    t.daemon = True
-    t.start()
-    return t
+
+    def _run(self):
+        seen = None
+        while self.store is not None and not self._stop.wait(0.5):
+            n = self._count()
+            if 0 < n < self.world:
+                seen = seen or time.monotonic()
+                if time.monotonic() - seen > self.GRACE_S:
+                    try:
+                        why = self.store.get(self._key() + "/msg").decode(errors="replace")
+                    except Exception:  # noqa: BLE001
+                        why = "a rank failed"
+                    self._bail(f"{why} ({n} of {self.world} ranks failed; the others were ended)")
+
+    def failed(self, msg):
+        """This rank's sub-record raised.  Returns when EVERY rank reported a failure of this phase (nobody is blocked); otherwise
+        the guard ends the process."""
+        if self.store is None:
+            return
+        try:
+            self.store.set(self._key() + "/msg", f"rank {self.rank}: {msg}")
+            self.store.add(self._key() + "/n", 1)
+        except Exception:  # noqa: BLE001
+            return
+        t0 = time.monotonic()
+        while self._count() < self.world and time.monotonic() - t0 < self.GRACE_S + 30.0:
+            time.sleep(0.2)
+
+    def cancel(self):
+        self._stop.set()
+        self._timer.cancel()
+
+
+def _job_store(dist):
+    """A client connection OF ITS OWN to the job's rendezvous store (MASTER_ADDR:MASTER_PORT: rank 0's, or the launcher agent's):
+    the process group's client serialises its operations, and a main thread waiting in a rendezvous would hold the guard's poll."""
+    try:
+        from datetime import timedelta
+        return dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), None, False,
+                             timeout=timedelta(seconds=20), wait_for_workers=False)
+    except Exception as e:  # noqa: BLE001  (no store: the time bound alone guards the phase)
+        print(f"[bench] no store connection for failure reports ({type(e).__name__}: {e})", file=sys.stderr)
+        return None
 
 
 def main():
@@ -992,7 +1068,8 @@ def main():
                     help="launcher / rendezvous / reduction plumbing only: no kernel, no GPU, `value` null (CPU test of --gpus N)")
     ap.add_argument("--dry-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--dry-stall-rank", type=int, default=-1, help=argparse.SUPPRESS)
-    ap.add_argument("--multi-gpu-timeout", type=float, default=900.0,
+    ap.add_argument("--dry-raise-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--multi-gpu-timeout", type=float, default=600.0,
                     help="N > 1: seconds the data-path phase (sharded_verify + the bounded loop sub-record) may take before the "
                          "headline is printed with the error recorded and every rank exits non-zero")
     ap.add_argument("--launch-timeout", type=float, default=3000.0,
@@ -1396,13 +1473,14 @@ def main():
         #   loop            BASELINE configs[3] at N = 2 ... 7 (tiers placed over the ranks), configs[4] at N >= 8 (replicated
         #                   drafts + sharded target, batch 16 per rank), real shapes, a few steps
         state = {"out": out, "phase": "sharded_verify"}
-        wd = _start_watchdog(args.multi_gpu_timeout, rank, state)
+        wd = _PhaseGuard(args.multi_gpu_timeout, rank, world, state, _job_store(dist))
         bufs = cpu_buf = None
         torch.cuda.empty_cache()
         try:
             sharded_rec = sharded_verify_step(torch, dist, device, rank, world, B, K, V, group=data_group)
         except Exception as e:  # noqa: BLE001
             sharded_rec = {"error": f"{type(e).__name__}: {e}"}
+            wd.failed(sharded_rec["error"])    # returns if every rank failed alike; a one-sided failure ends the job (non-zero)
         if out is not None:
             out["sharded_verify"] = sharded_rec
         state["phase"] = "loop"
@@ -1420,6 +1498,7 @@ def main():
                 rec["kind"] = plan["kind"]
         except Exception as e:  # noqa: BLE001  (the headline must not depend on the context record)
             rec = {"kind": plan["kind"], "error": f"{type(e).__name__}: {e}"}
+            wd.failed(rec["error"])
         wd.cancel()
         if out is not None:
             out["loop"] = rec

@@ -97,3 +97,24 @@ def test_a_rank_that_hangs_in_the_data_path_fails_the_job_but_the_headline_is_pr
     assert r.returncode != 0
     d = _one_line(r.stdout)
     assert d["n_gpus"] == 2 and "timed out" in d["loop"]["error"]
+
+
+def test_a_rank_whose_sub_record_raises_ends_the_job_in_seconds_not_at_the_time_bound():
+    """One rank raises in the data-path phase while the other waits in the exchange: the report goes through the rendezvous store,
+    the headline is printed with that rank's error and every rank exits non-zero -- long before --multi-gpu-timeout."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--dry-raise-rank", "1", "--multi-gpu-timeout", "120",
+                        "--launch-timeout", "200"], capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode != 0
+    assert time.monotonic() - t0 < 60
+    d = _one_line(r.stdout)
+    assert "rank 1" in d["loop"]["error"] and "injected" in d["loop"]["error"]
+
+
+def test_a_sub_record_that_raises_on_every_rank_is_recorded_and_the_job_ends_normally():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--dry-raise-rank", "2", "--multi-gpu-timeout", "120",
+                        "--launch-timeout", "200"], capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    assert "injected" in d["loop"]["error"] and d["loop"]["kind"] == "tiers"
