@@ -29,6 +29,7 @@
 // reduction slices that meet through f32 slabs and a ticket (see the launcher).
 //
 // Algorithmic HBM bytes: V*D*2 (weights once per 256 rows) + M*D*2; flops: 2*M*D*V.
+#define ASD_DPP_ASM_REDUCTIONS 1   // wave_max / wave_sum as one DPP instruction per step (lse_device.hpp)
 #include "lse_device.hpp"
 
 #ifndef ASD_LMHEAD_LAB

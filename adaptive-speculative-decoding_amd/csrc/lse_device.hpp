@@ -19,7 +19,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-static __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+// v_max3_f32 / v_max_f32 written out: `fmaxf` on a value that came out of integer unpacking (or out of a loop-carried
+// register) is preceded by a quieting `v_max_f32 x, x` per operand on this compiler; the instructions themselves return the
+// non-NaN operand like fmaxf does (IEEE mode), so the values are the same and two to three issues per 16-byte vector go away.
+static __device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+static __device__ __forceinline__ float max2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // (m2a, sa) (+) (m2b, sb) in the log2 domain
 static __device__ __forceinline__ void ms_merge(float& m2, float& s, float m2b, float sb) {
@@ -38,6 +50,50 @@ template <int CTRL, int ROW_MASK>
 static __device__ __forceinline__ float dpp_move(float identity, float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
+#if defined(ASD_DPP_ASM_REDUCTIONS)
+// ASD_DPP_ASM_REDUCTIONS (verify_accept.hip, lm_head_verify.hip: compiled with -ffp-contract=off, where it is bit-neutral) --
+// one DPP instruction per step: `v_max_f32_dpp v, v, v <ctrl>` / `v_add_f32_dpp` with bound_ctrl off leave a lane whose source
+// is out of range (or whose row is masked off) UNCHANGED -- which is max(v, -inf) / v + 0, what the builtin form (a v_mov_dpp
+// into an identity register, a quieting v_max, the operation: 3-4 issues per step) computed.  Same values, 6 issues instead of
+// 24 (max) / 14 (sum) per reduction -- the streaming kernels run one of each per tile.  `s_nop 1`: a DPP operand written by the
+// previous VALU instruction needs two wait states, and the compiler does not look into an asm block.
+static __device__ __forceinline__ float wave_max(float v) {
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+static __device__ __forceinline__ float wave_sum(float v) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#else
+// The builtin form.  Translation units compiled with floating-point contraction (the samplers) keep it: there the compiler fuses
+// the multiplication that feeds a wave_sum into the first step's addition, and their recorded outputs pin those bits.
 static __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_move<0x111, 0xf>(-INFINITY, v));
     v = fmaxf(v, dpp_move<0x112, 0xf>(-INFINITY, v));
@@ -56,6 +112,7 @@ static __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_move<0x143, 0xc>(0.0f, v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+#endif
 // all 64 lanes' (m2, s) -> one pair, valid (uniform) in every lane: max first, ONE rescale per lane
 static __device__ __forceinline__ void wave_merge(float& m2, float& s) {
     const float M = wave_max(m2);
@@ -89,11 +146,11 @@ static __device__ __forceinline__ void accum_t(const float (&x)[N], float c2, fl
         vmax = max3(x[0], x[1], x[2]);
         vmax = max3(vmax, x[3], x[4]);
         vmax = max3(vmax, x[5], x[6]);
-        vmax = fmaxf(vmax, x[7]);
+        vmax = max2(vmax, x[7]);
     } else {
-        vmax = fmaxf(max3(x[0], x[1], x[2]), x[3]);
+        vmax = max2(max3(x[0], x[1], x[2]), x[3]);
     }
-    const float M = fmaxf(m2, vmax * c2);
+    const float M = max2(m2, vmax * c2);
     const float scale = fast_exp2(m2 - M);
     float e[N];
     float w = 0.0f;
@@ -112,7 +169,7 @@ static __device__ __forceinline__ void accum_t(const float (&x)[N], float c2, fl
 
 // c2 = log2(e) / temperature: the per-element FMA constant, so temperature scaling costs nothing
 static __device__ __forceinline__ void accum_scalar(float x, float c2, float& m2, float& s) {
-    const float M = fmaxf(m2, x * c2);
+    const float M = max2(m2, x * c2);
     s = fmaf(s, fast_exp2(m2 - M), fast_exp2(fmaf(x, c2, -M)));
     m2 = M;
 }
@@ -121,8 +178,8 @@ static __device__ __forceinline__ void accum8(const float (&x)[8], float c2, flo
     float vmax = max3(x[0], x[1], x[2]);
     vmax = max3(vmax, x[3], x[4]);
     vmax = max3(vmax, x[5], x[6]);
-    vmax = fmaxf(vmax, x[7]);
-    const float M = fmaxf(m2, vmax * c2);
+    vmax = max2(vmax, x[7]);
+    const float M = max2(m2, vmax * c2);
     const float scale = fast_exp2(m2 - M);
     float e[8];
 #pragma unroll
@@ -133,8 +190,8 @@ static __device__ __forceinline__ void accum8(const float (&x)[8], float c2, flo
 }
 
 static __device__ __forceinline__ void accum4(const float (&x)[4], float c2, float& m2, float& s) {
-    const float vmax = fmaxf(max3(x[0], x[1], x[2]), x[3]);
-    const float M = fmaxf(m2, vmax * c2);
+    const float vmax = max2(max3(x[0], x[1], x[2]), x[3]);
+    const float M = max2(m2, vmax * c2);
     const float scale = fast_exp2(m2 - M);
     float e[4];
 #pragma unroll

@@ -68,6 +68,7 @@ __device__ unsigned long long* g_asd_stamps = nullptr;
 #define ASD_STAMP_AT(slot) do { } while (0)
 #endif
 
+#define ASD_DPP_ASM_REDUCTIONS 1   // wave_max / wave_sum as one DPP instruction per step (lse_device.hpp)
 #include "lse_device.hpp"
 #include "predictor_device.hpp"   // this TU is built with -ffp-contract=off (numpy / CPython parity of the epilogue)
 

@@ -27,7 +27,7 @@ from bench import N_STAGES, STAGE_COSTS, WORKLOADS, build_inputs, predictor_weig
 
 
 # variants >= 20 are the product code (ASD_LAB = 0) under other build switches
-SWITCHES = {20: ["-DASD_PARAMS_EARLY=1"], 21: ["-DASD_PARAMS_EARLY=0"]}
+SWITCHES = {20: ["-DASD_PARAMS_EARLY=1"], 21: ["-DASD_PARAMS_EARLY=0"], 22: ["-fno-slp-vectorize"]}
 
 
 def build_variant(n: int) -> str:
