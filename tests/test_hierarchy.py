@@ -274,7 +274,7 @@ def _sharded_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])          # 8: the rank count of BASELINE configs[4] (one sequence per rank here)
 def test_replicated_drafts_with_a_vocab_sharded_target(world):
     """BASELINE configs[4] in miniature: every rank drafts its slice and runs ITS rows through the target body, the
     target's lm_head is split over all ranks (hidden states all-gathered); the committed stream equals the one-rank run's
