@@ -267,6 +267,18 @@ def all_gather_any(parts_like: torch.Tensor, group=None):
     return parts
 
 
+def all_to_all_rows(rows: torch.Tensor, counts, group=None) -> torch.Tensor:
+    """rows [sum(counts), W]: rows [o_q, o_q + counts[q]) go to rank q; returns [world * counts[me], W] -- the pieces every rank
+    held of MY rows, in rank order.  One all-to-all (RCCL: ncclSend / ncclRecv pairs in one group); over gloo through the host."""
+    world, me = dist.get_world_size(group), dist.get_rank(group)
+    counts = [int(c) for c in counts]
+    staged = rows.is_cuda and host_staged(group)
+    src = rows.contiguous().cpu() if staged else rows.contiguous()
+    out = torch.empty((world * counts[me],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_to_all_single(out, src, output_split_sizes=[counts[me]] * world, input_split_sizes=counts, group=group)
+    return out.to(rows.device) if staged else out
+
+
 class VocabShardedVerifier:
     """Target lm_head split over the ranks of `group` along the vocabulary."""
 

@@ -316,6 +316,28 @@ class ShardedHead:
                 for r, p in enumerate(parts)]
         return torch.cat(cols, 1).contiguous()
 
+    def draw_rows_owned(self, j_all, counts):
+        """The batch-sharded target's form: sequence b belongs to ONE rank (rank q owns `counts[q]` consecutive sequences), so
+        the shard pieces are exchanged with one all-to-all -- rank q receives [counts[q], V/N] from every rank, (N - 1) / N of
+        ITS rows -- instead of all-gathering every sequence's row to every rank.  Returns the rank's own rows [counts[me], V]."""
+        from ..distributed import all_to_all_rows
+        Bt = int(j_all.shape[0])
+        sel = torch.arange(Bt, device=j_all.device)
+        piece = (self.m.lm_head(self._hid[sel, j_all]) * self.m.logit_scale).contiguous()  # [B, v1-v0]: my columns of EVERY row
+        widths = [shard_bounds(self.vocab, self.world, r)[1] - shard_bounds(self.vocab, self.world, r)[0] for r in range(self.world)]
+        width = max(widths)
+        if piece.shape[1] != width:
+            pad = torch.zeros((Bt, width), dtype=piece.dtype, device=piece.device)
+            pad[:, :piece.shape[1]] = piece
+            piece = pad
+        if self.world == 1:
+            return piece[:, :widths[0]].contiguous()
+        got = all_to_all_rows(piece, counts, self.group)                                   # [N * mine, width]
+        mine = int(counts[self.rank])
+        self.bytes_exchanged += (Bt - mine) * width * piece.element_size()                 # what this rank SENDS
+        got = got.view(self.world, mine, width)
+        return torch.cat([got[r, :, :widths[r]] for r in range(self.world)], 1).contiguous()
+
 
 # ------------------------------------------------------------------------------------------- tiers s >= 1
 class VerifyRole:
@@ -982,7 +1004,8 @@ class ShardedTargetRole:
         all-gather  tok [B/N,K] i32, lp_d [B/N,K] f32, p_0 [B/N] f64                  the drafts                 ~1.2 KB / rank
         all-gather  final hidden states [B/N, K+1, D] (storage dtype)                  body -> sharded head       2.36 MB / rank (B/N = 16, D = 8192)
         all-gather  (m2, s, g) [B,K,3] f32                                             inside ShardedHead.score   12 KB at B = 128
-        all-gather  the shard pieces [B, V/N] of ONE target row per sequence           inside ShardedHead.draw_rows
+        all-to-all  the shard pieces [B/N, V/N] of ONE target row per OWN sequence      inside ShardedHead.draw_rows_owned  4.3 MB / rank (B = 128, N = 8;
+                                                                                       round 4a all-gathered every row to every rank: 34 MB)
         all-reduce  MIN of the shortest sequence's length (8 bytes: every rank leaves the loop at the same step)
 
     and never a [B,K,V] tensor; each rank draws and commits only its own sequences.  Uniforms are drawn for the WHOLE batch from one seeded generator on every rank (as
@@ -996,6 +1019,14 @@ class ShardedTargetRole:
         self.st = _SeqState(prompt_local, max_new_tokens, cfg.draft_len)
         self.b1 = self.b0 + self.st.B
         dev = prompt_local.device
+        # sequences per rank of the head's group, in rank order (the all-to-all of the draw rows needs every rank's count)
+        n_ranks = head.world
+        if n_ranks > 1:
+            mine = torch.tensor([self.st.B], dtype=torch.int64, device=dev)
+            self.counts = [int(c.item()) for c in all_gather_any(mine, group)]
+        else:
+            self.counts = [self.st.B]
+        assert sum(self.counts) == self.Bt and sum(self.counts[:head.rank]) == self.b0, "the ranks' slices must tile the batch in rank order"
         self.gen = _dev_gen(dev, cfg.seed + 7919 * 1)            # VerifyRole's generator of stage 1: the same uniforms
         self.inv_t = float(np.float32(1.0 / cfg.temperature))
         self.L = len(cfg.stage_costs)
@@ -1058,9 +1089,8 @@ class ShardedTargetRole:
         K, dev = self.cfg.draft_len, self.st.tokens.device
         Bt = self.Bt
         j_all = self._n_acc.to(torch.int64)
-        t_rows = self.head.draw_rows(torch.arange(Bt, device=dev), j_all)          # [B, V]
         sl = slice(self.b0, self.b1)
-        t_rows, j = t_rows[sl].contiguous(), j_all[sl]
+        t_rows, j = self.head.draw_rows_owned(j_all, self.counts), j_all[sl]       # [B/N, V]: the rank's own rows
         m = self.st.B
         d_full = torch.zeros_like(t_rows)
         thr = torch.full((m,), float("-inf"), dtype=torch.float32, device=dev)

@@ -301,6 +301,15 @@ def test_rank_driver_over_a_one_rank_rccl_group_with_loopback():
         looped = {k: v for k, v in got.bytes_sent.items() if k.endswith("(loopback)")}
         assert set(looped) >= {"draft (loopback)", "verdict (loopback)", "drawn (loopback)", "final (loopback)"}
         assert all(v > 0 for v in looped.values())
+        # the collectives of the sharded-target loop (configs[4]) on the same RCCL communicator, device tensors: all-gather of the
+        # hidden states, the all-to-all of the draw-row pieces, the MIN all-reduce of the loop exit
+        from asd_amd.distributed import all_gather_any, all_to_all_rows
+        x = torch.arange(6 * 8, device=dev, dtype=torch.float32).view(6, 8).to(dt)
+        assert torch.equal(torch.cat(all_gather_any(x), 0), x)
+        assert torch.equal(all_to_all_rows(x, [6]), x)
+        m_ = torch.tensor([41], device=dev, dtype=torch.int64)
+        dist.all_reduce(m_, op=dist.ReduceOp.MIN)
+        assert int(m_.item()) == 41
     finally:
         dist.destroy_process_group()
 

@@ -618,19 +618,26 @@ def test_workspace_is_all_zero_after_every_call_form_and_shared_across_shapes(K_
         clean()
 
 
-@pytest.mark.parametrize("form", ["split", "fused_rows", "fused_split"])
+@pytest.mark.parametrize("form", ["split", "fused_rows", "fused_split", "fused_rows_256x128"])
 def test_a_withheld_hand_off_poisons_the_result_instead_of_folding_a_zero(K_, form):
     """asd_debug_verify_withhold makes one workgroup skip its hand-off store: the finisher's bounded wait must end in
     NaN / reject (split rows) or score = NaN, k* = L - 1, stop = 0 (in-kernel epilogue) for THAT row / sequence only,
     and leave the workspace clean for the next call."""
     import torch
     V = 40000                                               # wide enough for ceil(CUs / rows) = 4 slices of >= one tile per wave
-    B = 32 if form == "fused_rows" else 8
+    B = 32 if form.startswith("fused_rows") else 8
     c = make_verify_case(B, 8, V, O.DT_BF16, seed=B + 7)
     lg = to_device_logits(c["logits"], c["dtype"]).view(B, 8, V)
     tok, lp_d, u = (torch.from_numpy(c[k]).cuda() for k in ("tok", "lp_d", "u"))
     ws = K_.VerifyWorkspace(B, 8, V)
     feat, packed, Cc = _fused_args(K_, B)
+    dims = (64, 32)
+    if form == "fused_rows_256x128":                        # the eight-wave epilogue (k_verify<..., EPI = 2>): all waves of the finisher's
+        rng = np.random.default_rng(3)                      # workgroup meet at a barrier BEFORE the loss is detected
+        packed = K_.pack_mlp_weights((rng.standard_normal((128, 256)) / 16).astype(np.float32), (rng.standard_normal(128) * 0.1).astype(np.float32),
+                                     (rng.standard_normal((1, 128)) / 8).astype(np.float32), np.array([0.05], np.float32))
+        feat = torch.from_numpy((rng.standard_normal((B, 256)) * 0.3).astype(np.float32)).cuda()
+        dims = (256, 128)
     cus = K_.device_cu_count()
     S = 1 if B * 8 >= cus else -(-cus // (B * 8))          # the launcher's split count (rows < CUs: ceil(CUs / rows))
     bad_b, bad_k = 3, 5
@@ -642,14 +649,14 @@ def test_a_withheld_hand_off_poisons_the_result_instead_of_folding_a_zero(K_, fo
             if form == "split":
                 v, s = K_.verify_accept(lg, tok, lp_d, u, ws), None
             else:
-                v, s = K_.verify_accept_fused(lg, tok, lp_d, u, ws, feat, packed, 64, 32, stage_idx=0, L=3, p_hist=ph, Cc=Cc, lam=0.8)
+                v, s = K_.verify_accept_fused(lg, tok, lp_d, u, ws, feat, packed, *dims, stage_idx=0, L=3, p_hist=ph, Cc=Cc, lam=0.8)
             torch.cuda.synchronize()
         finally:
             lib.asd_debug_verify_withhold(-1)
     lp = v.lp_target.cpu().numpy()
     acc = v.accept.cpu().numpy()
     others = np.ones((B, 8), bool)
-    if form == "fused_rows":                                # rows finish themselves: only the epilogue lost its input
+    if form.startswith("fused_rows"):                       # rows finish themselves: only the epilogue lost its input
         np.testing.assert_allclose(lp, c["ref"]["lp_t64"], atol=1e-5, rtol=1e-6)
         assert np.array_equal(acc, c["ref"]["accept"])
     else:

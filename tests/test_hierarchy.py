@@ -268,7 +268,8 @@ def _sharded_worker(rank, world, port, ret):
         # exchange volume per rank: hidden states of its rows + triples + one row piece per sequence and step, never [B,K,V]
         D_ = t.m.shape.hidden
         per_step = (head.bytes_exchanged + t.bytes_exchanged) / got.steps
-        assert per_step <= ((b1 - b0) * (K + 1) * D_ * 4 + (b1 - b0) * (K * 8 + 8) + Bt * K * 12 + Bt * (V // world + 1) * 4) * (world - 1) + 64
+        # (the draw rows: one all-to-all -- a rank sends its V/N columns of the OTHER ranks' sequences only)
+        assert per_step <= ((b1 - b0) * (K + 1) * D_ * 4 + (b1 - b0) * (K * 8 + 8) + Bt * K * 12) * (world - 1) + (Bt - (b1 - b0)) * (V // world + 1) * 4 + 64
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
