@@ -19,6 +19,9 @@ bench:
 golden:           ## regenerate tests/golden from the reference's own files (dev container only)
 	PYTHONDONTWRITEBYTECODE=1 $(PY) oracle/gen_golden.py
 
+test-hooks:       ## the TEST build of the library (libasd_hip_test.so: product objects + the asd_debug_* switches under -DASD_TEST_HOOKS)
+	$(PY) adaptive-speculative-decoding_amd/build.py --test-hooks
+
 asan-host:        ## host side of the launchers under AddressSanitizer + UBSan (CPU only: the ABI / argument-check tests)
 	$(PY) adaptive-speculative-decoding_amd/build.py --asan
 	ASD_LIB_PATH=$(CURDIR)/adaptive-speculative-decoding_amd/lib/libasd_hip_asan.so \
@@ -29,4 +32,4 @@ asan-host:        ## host side of the launchers under AddressSanitizer + UBSan (
 clean:
 	rm -rf adaptive-speculative-decoding_amd/lib oracle/_build gpurun_out
 
-.PHONY: build test-cpu test-gpu smoke bench golden asan-host clean
+.PHONY: build test-cpu test-gpu smoke bench golden test-hooks asan-host clean
