@@ -1296,6 +1296,63 @@ def main():
             torch.cuda.synchronize()
             fused_runs.append(e0.elapsed_time(e1) / reps)
 
+    # side measurement (never `value`): TWO independent batches in flight -- the same one-launch step on two streams with their own
+    # workspaces and outputs, forked and joined inside one hipGraph.  What separates a serial step from the 9.7 us its bytes take at
+    # 8 TB/s is mostly the ramp to the first byte and the tail behind the last one; a second batch hides them.
+    two_stream = None
+    if args.fused and world == 1 and not args.no_other_workloads:
+        try:
+            ws_b = Kmod.VerifyWorkspace(B, K, V, torch.bfloat16, device)
+            score_b, k_star_b, stop_b, p_hist_b = torch.empty_like(score), torch.empty_like(k_star), torch.empty_like(stop), p_hist.clone()
+
+            def fused_step_b(buf, st):
+                o = buf["out"]
+                rc = lib.asd_verify_accept_fused(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(),
+                                                 buf["u"].data_ptr(), B, K, V, o.lp_target.data_ptr(), o.accept.data_ptr(),
+                                                 o.n_acc.data_ptr(), o.accept_bits.data_ptr(), ws_b.buf.data_ptr(), ws_b.bytes,
+                                                 feat.data_ptr(), 64, 5, packed.data_ptr(), 64, 32, 1, 100, 1.0, 1.0,
+                                                 p_hist_b.data_ptr(), Cc.data_ptr(), 1.0, N_STAGES, 0, 0, None, score_b.data_ptr(),
+                                                 k_star_b.data_ptr(), stop_b.data_ptr(), None, None, st)
+                if rc:
+                    raise RuntimeError(f"asd_verify_accept_fused rc={rc}")
+            pairs = 12
+            sa, sb = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+            torch.cuda.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                main_s = torch.cuda.current_stream()
+                ev = torch.cuda.Event()
+                ev.record(main_s)
+                sa.wait_event(ev)
+                sb.wait_event(ev)
+                for j in range(pairs):
+                    fused_step(bufs[(2 * j) % nbuf], sa.cuda_stream)
+                    fused_step_b(bufs[(2 * j + 1) % nbuf], sb.cuda_stream)
+                ea, eb = torch.cuda.Event(), torch.cuda.Event()
+                ea.record(sa)
+                eb.record(sb)
+                main_s.wait_event(ea)
+                main_s.wait_event(eb)
+            g2.replay()
+            torch.cuda.synchronize()
+            ts_runs = []
+            for _ in range(5):
+                e0.record()
+                for _ in range(10):
+                    g2.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                ts_runs.append(e0.elapsed_time(e1) / (10 * 2 * pairs))
+            del g2
+            ts_ms = sum(ts_runs) / len(ts_runs)
+            two_stream = {"what": "the one-launch step on TWO streams (two independent batches in flight, own workspaces and outputs), "
+                                  f"{2 * pairs} steps per hipGraph replay; per-step time = replay time / steps.  Context only: `value` is the serial step",
+                          "ms_per_step": ts_ms, "ms_per_step_runs": ts_runs,
+                          "achieved_GBs": bytes_per_launch / (ts_ms * 1e-3) / 1e9, "frac_of_8TBs": bytes_per_launch / (ts_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        except Exception as e:  # noqa: BLE001  (context record: the headline does not depend on it)
+            two_stream = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize()
+
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1458,6 +1515,8 @@ def main():
                 "achieved": bytes_per_launch / (plain_ms * 1e-3) / 1e9,
                 "frac": bytes_per_launch / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "same algorithmic bytes, same measurement; NOT the kernel `value` was computed from"}
+        if two_stream is not None:
+            out["roofline"]["two_batches_in_flight"] = two_stream
         if others:
             out["roofline"]["other_workloads_kernel_only"] = others
         if loop_rec is not None:
