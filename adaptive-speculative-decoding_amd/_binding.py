@@ -140,10 +140,10 @@ def load_test_library() -> C.CDLL:
     global _test_lib
     if _test_lib is not None:
         return _test_lib
+    load_library()                      # torch's HIP runtime first (see below) -- and BEFORE taking the lock, which load_library takes too
     with _lock:
         if _test_lib is None:
             import importlib.util
-            load_library()                                       # torch's HIP runtime first (see below)
             spec = importlib.util.spec_from_file_location("asd_amd_build", os.path.join(_HERE, "build.py"))
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)

@@ -19,6 +19,10 @@ from tests.helpers import encode_logits, to_device_logits  # noqa: E402
 
 
 def main():
+    import faulthandler
+    if os.environ.get("ASD_SOAK_DUMP_AFTER"):   # where is it? (a Python stack of every thread after N seconds, repeated)
+        faulthandler.dump_traceback_later(float(os.environ["ASD_SOAK_DUMP_AFTER"]), repeat=True, file=sys.stdout)
+    verbose = os.environ.get("ASD_SOAK_VERBOSE") == "1"
     hooks = K.test_hooks().__enter__()          # the TEST build of the library for the whole program (asd_debug_draft_groups)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
@@ -45,6 +49,8 @@ def main():
         lg = to_device_logits(store, dtype).view(B, V)
         groups = int(rng.choice([0, 0, -1, 1, 2, 4, 8, 16, 32]))            # 0: heuristic; -1: the streaming form; else forced
         hooks.asd_debug_draft_groups(groups if groups <= 0 or B * groups <= 256 else 0)
+        if verbose:
+            print(f"case {it}: B={B} V={V} dtype={dtype} scale={scale} T={T} top_p={top_p} groups={groups}", flush=True)
         samp = K.DraftSampler(B, V, lg.dtype)
         d = samp(lg, torch.from_numpy(r).cuda(), inv_t, top_p)
         torch.cuda.synchronize()
@@ -68,6 +74,8 @@ def main():
         sb = encode_logits((rng.standard_normal((B, V)) * max(scale, 0.5)).astype(np.float32), dtype)
         n_acc = rng.integers(0, Kd + 1, B).astype(np.int32)
         want, margin = O.residual_sample(st, sd, dtype, n_acc, r, B, Kd, V, bonus=sb, inv_temperature=inv_t)
+        if verbose:
+            print(f"case {it}: residual draw, n_acc {n_acc.tolist()[:8]}", flush=True)
         t3, d3 = to_device_logits(st, dtype).view(B, Kd, V), to_device_logits(sd, dtype).view(B, Kd, V)
         got = K.ResidualSampler(B, V, t3.dtype)(t3, d3, torch.from_numpy(n_acc).cuda(), torch.from_numpy(r).cuda(),
                                                 to_device_logits(sb, dtype).view(B, V), inv_t)
@@ -83,6 +91,8 @@ def main():
             g = got.cpu().numpy()
             assert ((g >= 0) & (g < V)).all(), (it, "residual range", B, V)
         n_res += int(okr.sum())
+        if (it + 1) % 10 == 0:
+            print(f"{it + 1} cases ok", flush=True)
     print(f"fuzz: {cases} cases passed; thresholds compared {n_thr}, tokens {n_tok}, residual tokens {n_res}")
 
 

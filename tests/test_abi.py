@@ -119,3 +119,16 @@ def test_linear_plan_is_sane_without_a_gpu():
     assert lib.asd_linear_slices(32, 59136, 8192) == 1            # 231 column blocks on 256 CUs: one round, no slicing
     assert lib.asd_linear_slices(32, 3584, 3584) > 1              # 14 column blocks
     assert lib.asd_linear_slices(32, 3584, 100) == 0 and lib.asd_linear_workspace_bytes(32, 3584, 100) == 0   # D % 64
+
+
+def test_the_test_library_can_be_the_first_thing_a_fresh_process_loads():
+    """load_test_library() loads the product library first; it must not do so while holding the lock load_library() takes (a
+    stand-alone soak script whose first call was `kernels.test_hooks()` waited for ever; the suite never saw it because its
+    fixtures load the product library first)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from asd_amd import _binding as B; lib = B.use_test_library().__enter__(); "
+            "print(lib.asd_version(), hasattr(lib, 'asd_debug_draft_groups'))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == ["300", "True"]
