@@ -342,14 +342,24 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
         ASD_REDUCE_TILE(ra, ta);
         if (first) { ASD_STAMP_AT(1); first = false; }
         ta = tn;
+#if defined(ASD_LAB) && ASD_LAB == 10    // lab: NO loads in the loop (the registers of the first two tiles are consumed again and again): the loop's VALU + claim time alone
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) asm volatile("" : "+v"(ra[j]));
+#else
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) ra[j] = load16<NT>(rsrc, ta * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
+#endif
         if (tb >= n_tiles) break;
         ASD_CLAIM(tn);
         ASD_REDUCE_TILE(rb, tb);
         tb = tn;
+#if defined(ASD_LAB) && ASD_LAB == 10
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) asm volatile("" : "+v"(rb[j]));
+#else
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) rb[j] = load16<NT>(rsrc, tb * kTileBytes + static_cast<uint32_t>(j) * 1024u + lane_off);
+#endif
     }
 #undef ASD_CLAIM
 #undef ASD_REDUCE_TILE
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(THREADS) void k_verify(const void* a_logits, const 
     if (lane == 0 && g_asd_stamps)   // per-wave stream end, after the per-workgroup records
         g_asd_stamps[static_cast<size_t>(gridDim.x * gridDim.y) * 16 + static_cast<size_t>(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
-#if defined(ASD_LAB) && ASD_LAB == 8     // lab: the kernel ends behind the stream (no barrier, no fold, no tail): ramp + stream + per-tile math alone
+#if defined(ASD_LAB) && (ASD_LAB == 8 || ASD_LAB == 10)     // lab: the kernel ends behind the stream (no barrier, no fold, no tail): ramp + stream + per-tile math alone
     if (lane == 0 && stage[0] == 0x1234567812345678ull) p.lp_t[row] = 0.0f;
     return;
 #endif

@@ -77,7 +77,7 @@ def main():
         fns[f"fused/{n}"] = ("fused", ff)
         if n == variants[0]:
             fns["plain"] = ("plain", pl)
-        elif n in (4, 8, 9) or n >= 20:
+        elif n in (4, 8, 9, 10) or n >= 20:
             fns[f"plain/{n}"] = ("plain", pl)
 
     big = None
