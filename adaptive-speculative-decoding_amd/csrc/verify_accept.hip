@@ -777,12 +777,27 @@ struct Geometry {
 //                 less to drain at the end than a 4-KiB one, while two tiles per wave still keep 48 KiB per CU in flight.
 //   rows <  CUs : split rows until ~one 512-lane workgroup per CU exists (B=8: S=4, 8.4 us); a slice is
 //                 never cut below one tile per wave.
-Geometry choose_geometry(int R, int K, int V, int dtype, int cus) {
+//   rows >= CUs, not a multiple of them (round 4): with one workgroup per row the CUs that hold one row more than the others
+//                 finish alone, and the few workgroups left cannot keep the HBM busy (B = 33: 21.7 us against 15.5 at B = 32;
+//                 B = 65: 33.4 against 26.6).  When the last round of rows fills less than ~60 % of the CUs the rows are cut
+//                 into 4 (2) slices, so that every CU gets nearly the same bytes: B = 33 17.5 us, 40: 19.3 (22.3), 48: 21.5
+//                 (22.8), 65: 29.3, 100: 40.9 (44.7), 130: 53.0 (56.3) -- profiles/r04_sweep_batch_splits*.json.  The slices
+//                 pay the granule hand-off (4.2), which is why full rounds (B = 32, 64, 96, 128) stay unsplit.
+Geometry choose_geometry(int R, int K, int V, int dtype, int cus, bool whole_rows_only = false) {
     Geometry g{1, 512, 3, 1};
-    if (R >= cus) return g;
+    const int64_t row_bytes = static_cast<int64_t>(V) * dtype_size(dtype);
+    if (R >= cus) {
+        const int rounds = R / cus, rest = R % cus;
+        if (whole_rows_only || rest == 0 || rounds >= 6) return g;
+        int64_t want = 10 * rest < 4 * cus ? 4 : (10 * rest < 6 * cus && rounds < 3 ? 2 : 1);
+        int64_t cap = row_bytes / (static_cast<int64_t>(g.threads / 64) * g.unroll * 1024);   // a slice is never cut below one tile per wave
+        if (want > cap) want = cap;
+        if (want > max_splits_for(K)) want = max_splits_for(K);
+        g.splits = want < 1 ? 1 : static_cast<int>(want);
+        return g;
+    }
     g.threads = 512;
     g.unroll = 2;
-    const int64_t row_bytes = static_cast<int64_t>(V) * dtype_size(dtype);
     int64_t want = (static_cast<int64_t>(cus) + R - 1) / (R > 0 ? R : 1);
     int64_t cap = row_bytes / (static_cast<int64_t>(g.threads / 64) * g.unroll * 1024);
     if (cap < 1) cap = 1;
@@ -847,7 +862,8 @@ int launch_verify(VerifyParams p, int dtype, void* workspace, size_t workspace_b
     const int64_t R = static_cast<int64_t>(p.B) * p.K;
     if (R > INT32_MAX) return ASD_ERR_UNSUPPORTED;
 
-    const Geometry h = choose_geometry(static_cast<int>(R), p.K, p.V, dtype, current_device_cus());
+    // (the (m2, s, t) instantiation and the eight-wave 256 x 128 epilogue exist for one workgroup per row only)
+    const Geometry h = choose_geometry(static_cast<int>(R), p.K, p.V, dtype, current_device_cus(), p.row_entropy != nullptr || p.fused == 2);
     const bool auto_unroll = g.unroll <= 0, auto_splits = g.splits <= 0;
     if (g.splits <= 0) g.splits = h.splits;
     if (g.threads <= 0) g.threads = h.threads;

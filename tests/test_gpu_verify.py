@@ -681,3 +681,35 @@ def test_a_withheld_hand_off_poisons_the_result_instead_of_folding_a_zero(K_, fo
     torch.cuda.synchronize()
     assert np.array_equal(again.accept.cpu().numpy(), c["ref"]["accept"])
     assert ws.status() == 0
+
+
+@pytest.mark.parametrize("B,K,V", [(33, 8, 152064), (40, 8, 30000), (48, 8, 30000), (65, 8, 30000), (100, 4, 20000), (130, 8, 9000), (36, 8, 1000)])
+def test_rows_that_do_not_fill_the_cus_evenly_are_cut_into_slices(K_, B, K, V):
+    """rows >= CUs but not a multiple of them: the heuristic cuts the rows into 4 (2) slices so that every CU gets nearly the same
+    bytes (choose_geometry).  Same results as the oracle, the one-launch step equals two launches bit for bit (both take the same
+    geometry), the workspace comes back clean; the (m2, s, t) instantiation and the 256 x 128 epilogue keep whole rows."""
+    import torch
+    case = make_verify_case(B, K, V, O.DT_BF16, seed=B * 3 + K)
+    lg = to_device_logits(case["logits"], case["dtype"]).view(B, K, V)
+    tok, lp_d, u = (torch.from_numpy(case[k]).cuda() for k in ("tok", "lp_d", "u"))
+    ws = K_.VerifyWorkspace(B, K, V)
+    v = K_.verify_accept(lg, tok, lp_d, u, ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(v.accept.cpu().numpy(), case["ref"]["accept"]) and np.array_equal(v.n_acc.cpu().numpy(), case["ref"]["n_acc"])
+    np.testing.assert_allclose(v.lp_target.cpu().numpy(), case["ref"]["lp_t64"], atol=1e-5, rtol=1e-6)
+    forced = K_.verify_accept(lg, tok, lp_d, u, ws, splits=1)                       # whole rows: the same decisions
+    assert np.array_equal(forced.accept.cpu().numpy(), case["ref"]["accept"])
+    feat, packed, Cc = _fused_args(K_, B)
+    ph1 = torch.ones((B, 3), dtype=torch.float64, device="cuda")
+    ph2 = ph1.clone()
+    s1 = K_.predictor_stop(feat, packed, 64, 32, stage_idx=0, L=3, lp=v.lp_target, stats_col=5, p_hist=ph1, Cc=Cc, lam=0.8)
+    v2, s2 = K_.verify_accept_fused(lg, tok, lp_d, u, ws, feat, packed, 64, 32, stage_idx=0, L=3, stats_col=5, p_hist=ph2, Cc=Cc, lam=0.8)
+    torch.cuda.synchronize()
+    for a, b in ((v.lp_target, v2.lp_target), (v.accept_bits, v2.accept_bits), (v.n_acc, v2.n_acc), (s1.score, s2.score), (s1.k_star, s2.k_star),
+                 (s1.stop, s2.stop), (ph1, ph2)):
+        assert torch.equal(a, b)
+    st = K_.verify_accept_stats(lg, tok, lp_d, u, ws) if K <= 32 else None
+    torch.cuda.synchronize()
+    if st is not None:
+        assert np.array_equal(st[0].accept.cpu().numpy(), case["ref"]["accept"])
+    assert int(ws.buf.count_nonzero()) == 0 and ws.status() == 0

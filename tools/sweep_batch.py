@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="8,16,24,32,40,48,64,96,128,192,256")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep_batch.json"))
+    ap.add_argument("--splits", default="0", help="forced split counts to time beside the heuristic (0), plain kernel only: e.g. 0,2,4")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     Kk, V = 8, 152064
@@ -55,7 +56,20 @@ def main():
                                                None, None, torch.cuda.current_stream().cuda_stream)
         nb = algorithmic_bytes(B, Kk, V)
         rec = {"batch": B, "rows": B * Kk, "algorithmic_bytes": nb}
-        for name, fn in (("plain", plain), ("one_launch", fused)):
+        import ctypes
+        from asd_amd._binding import verify_options
+        forced = []
+        for S in [int(x) for x in a.splits.split(",") if int(x) > 0]:
+            opt = verify_options(1.0, S, 0, 0, -1)
+
+            def plain_s(buf, opt=opt):
+                o = buf["out"]
+                return lib.asd_verify_accept_ex(buf["logits"].data_ptr(), 1, V, buf["tok"].data_ptr(), buf["lp_d"].data_ptr(), buf["u"].data_ptr(), B, Kk, V,
+                                                o.lp_target.data_ptr(), o.accept.data_ptr(), o.n_acc.data_ptr(), o.accept_bits.data_ptr(),
+                                                ws.buf.data_ptr(), ws.bytes, ctypes.addressof(opt), torch.cuda.current_stream().cuda_stream)
+            if plain_s(bufs[0]) == 0:
+                forced.append((f"plain_S{S}", plain_s))
+        for name, fn in [("plain", plain), ("one_launch", fused)] + forced:
             for i in range(max(400, int(60e-3 / (nb / 4.0e12)))):     # settle: clocks / memory power state
                 assert fn(bufs[i % nbuf]) == 0
             torch.cuda.synchronize()
