@@ -775,37 +775,39 @@ struct Geometry {
 //                 2- and 4-KiB tiles and 15.3 for 1024 lanes x 2 KiB; B=128: 48.1 us = 6.47 TB/s).  A 304 KB row is 101.4 tiles
 //                 of 3 KiB: the eight waves of the workgroup end within one tile of each other, and a 3-KiB tile is a third
 //                 less to drain at the end than a 4-KiB one, while two tiles per wave still keep 48 KiB per CU in flight.
-//   rows <  CUs : split rows until ~one 512-lane workgroup per CU exists (B=8: S=4, 8.4 us); a slice is
-//                 never cut below one tile per wave.
-//   rows >= CUs, not a multiple of them (round 4): with one workgroup per row the CUs that hold one row more than the others
-//                 finish alone, and the few workgroups left cannot keep the HBM busy (B = 33: 21.7 us against 15.5 at B = 32;
-//                 B = 65: 33.4 against 26.6).  When the last round of rows fills less than ~60 % of the CUs the rows are cut
-//                 into 4 (2) slices, so that every CU gets nearly the same bytes: B = 33 17.5 us, 40: 19.3 (22.3), 48: 21.5
-//                 (22.8), 65: 29.3, 100: 40.9 (44.7), 130: 53.0 (56.3) -- profiles/r04_sweep_batch_splits*.json.  The slices
-//                 pay the granule hand-off (4.2), which is why full rounds (B = 32, 64, 96, 128) stay unsplit.
+//   slices (round 4: ONE rule for every row count, fitted to forced-slice sweeps at 22 row counts from 32 to 1040 rows,
+//                 profiles/r04_sweep_small_batch_splits.json, r04_sweep_batch_splits{,2}.json; it picks the measured best or a count
+//                 within 1.3 % of it in all of them): the rows are cut into the S slices that minimise
+//                     est(S) = a * max(ceil(R S / CUs) / S, 1.05 R / CUs)  +  0.2 us * R S / CUs ,   a = 6 us per 304-KB row
+//                 -- the bytes of the fullest CU (in rows), floored by the chip-wide HBM time, plus a fixed cost per workgroup a CU
+//                 runs (ramp, granule hand-off).  With one workgroup per row the CUs that hold one row more than the others finish
+//                 alone, and the few workgroups left cannot keep the HBM busy (B = 33: 21.7 us against 15.5 at B = 32; B = 65: 33.4
+//                 against 26.6); few rows leave CUs idle.  Full rounds (B = 32, 64, 96, 128: R a multiple of the CUs) stay whole.
+//                 A slice is never cut below one tile per wave.  Geometry: whole rows 512 lanes x 3 KiB; slices of fewer rows than
+//                 CUs 512 x 2 KiB (B = 8: S = 4), of more 512 x 3 KiB.
 Geometry choose_geometry(int R, int K, int V, int dtype, int cus, bool whole_rows_only = false) {
     Geometry g{1, 512, 3, 1};
+    if (R <= 0 || cus <= 0 || whole_rows_only) return g;
+    // full rounds; a last round that fills >= 60 % of the CUs still saturates the HBM on its own (B = 52, 56: whole rows measured
+    // best, the estimate's one systematic miss); beyond six rounds the dispatcher balances (unmeasured: left whole)
+    if (R >= cus && (R % cus == 0 || 10 * (R % cus) >= 6 * cus || R / cus >= 6)) return g;
     const int64_t row_bytes = static_cast<int64_t>(V) * dtype_size(dtype);
-    if (R >= cus) {
-        const int rounds = R / cus, rest = R % cus;
-        if (whole_rows_only || rest == 0 || rounds >= 6) return g;
-        int64_t want = 10 * rest < 4 * cus ? 4 : (10 * rest < 6 * cus && rounds < 3 ? 2 : 1);
-        int64_t cap = row_bytes / (static_cast<int64_t>(g.threads / 64) * g.unroll * 1024);   // a slice is never cut below one tile per wave
-        if (want > cap) want = cap;
-        if (want > max_splits_for(K)) want = max_splits_for(K);
-        g.splits = want < 1 ? 1 : static_cast<int>(want);
-        return g;
-    }
-    g.threads = 512;
-    g.unroll = 2;
-    int64_t want = (static_cast<int64_t>(cus) + R - 1) / (R > 0 ? R : 1);
-    int64_t cap = row_bytes / (static_cast<int64_t>(g.threads / 64) * g.unroll * 1024);
+    const int unroll_sliced = R >= cus ? 3 : 2;
+    int64_t cap = row_bytes / (static_cast<int64_t>(g.threads / 64) * unroll_sliced * 1024);
+    if (cap > max_splits_for(K)) cap = max_splits_for(K);
+    if (cap > (R >= cus ? 8 : 16)) cap = R >= cus ? 8 : 16;
     if (cap < 1) cap = 1;
-    if (want > cap) want = cap;
-    const int smax = max_splits_for(K);
-    if (want > smax) want = smax;
-    if (want < 1) want = 1;
-    g.splits = static_cast<int>(want);
+    const double a = 6.0 * static_cast<double>(row_bytes) / 304128.0, q = static_cast<double>(R) / cus;
+    int best = 1;
+    double best_est = 0.0;
+    for (int S = 1; S <= cap; ++S) {
+        const int64_t wgs = static_cast<int64_t>(R) * S;
+        const double load = static_cast<double>((wgs + cus - 1) / cus) / S;
+        const double est = a * (load > 1.05 * q ? load : 1.05 * q) + 0.2 * q * S;
+        if (S == 1 || est < best_est - 1e-9) { best = S; best_est = est; }
+    }
+    g.splits = best;
+    if (best > 1) g.unroll = unroll_sliced;
     return g;
 }
 
@@ -1061,8 +1063,11 @@ ASD_EXPORT int asd_verify_accept_fused_ex(const void* logits, int dtype, int64_t
     // ... and, with one workgroup per row (rows >= CUs, nothing forced), the 256 -> 128 -> 1 predictor of the reference's server
     // (src/serving/server.py:168): its first layer is cut over the eight waves of the finisher's workgroup
     const bool default_geometry = !opt || (opt->splits <= 0 && opt->threads <= 0 && opt->unroll <= 0);
+    // -- where the heuristic keeps whole rows: a row count it would cut into slices takes the two-launch route, so that the
+    // results stay those of asd_verify_accept_ex at the same arguments bit for bit
     const bool in_kernel2 = in_dim == kEpi2In && hidden == kEpi2Hid && default_geometry && L <= kDecidePrefetch && K <= kEpiInKernelMaxK &&
-                            static_cast<int64_t>(B) * K >= current_device_cus();
+                            static_cast<int64_t>(B) * K >= current_device_cus() && static_cast<int64_t>(B) * K <= INT32_MAX &&
+                            choose_geometry(static_cast<int>(static_cast<int64_t>(B) * K), K, V, dtype, current_device_cus()).splits == 1;
     if (!in_kernel && !in_kernel2) {
         const int rc = asd_verify_accept_ex(logits, dtype, ld_row, tok, lp_draft, u, B, K, V, lp_target, accept, n_acc,
                                             accept_bits, workspace, workspace_bytes, opt, stream);

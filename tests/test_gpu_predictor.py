@@ -237,11 +237,12 @@ def test_predictor_stop_256x128_latency_form_matches_the_oracle(K_, B, K):
 
 
 @pytest.mark.parametrize("B,K,V,T", [(32, 8, 30000, 1.0), (64, 4, 20000, 0.7), (16, 16, 9000, 1.0), (32, 8, 152064, 0.7),
-                                     (8, 8, 30000, 1.0), (40, 32, 5000, 1.0)])
+                                     (8, 8, 30000, 1.0), (40, 32, 5000, 1.0), (100, 8, 50257, 1.3), (33, 8, 30000, 1.0)])
 def test_in_kernel_epilogue_256x128_equals_two_launches(K_, B, K, V, T):
     """asd_verify_accept_fused_ex with the 256 -> 128 -> 1 predictor == asd_verify_accept_ex + asd_predictor_stop, bit for bit:
     in-kernel (k_verify<..., EPI = 2>: the first layer cut over the eight waves of the finisher's workgroup) with one workgroup per
-    row and K <= 16; split rows (B * K < CUs) and longer drafts take the two-launch route inside the same entry point."""
+    row and K <= 16; split rows (B * K < CUs, or a row count the geometry heuristic cuts into balanced slices: 100 x 8, 33 x 8) and
+    longer drafts take the two-launch route inside the same entry point."""
     import torch
     from tests.helpers import make_verify_case, to_device_logits
     w1, b1, w2, b2 = _w256()
