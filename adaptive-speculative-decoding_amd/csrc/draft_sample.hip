@@ -769,13 +769,16 @@ DgLayout dg_layout(int B, int n_tiles) {
 inline int tiles_per_wave(int n_tiles, int G) { return ((n_tiles + G - 1) / G + kDrWaves - 1) / kDrWaves; }
 
 // workgroups per row: ~one workgroup per CU while every workgroup keeps >= 8 tiles; 0 = the row does not fit the registers of
-// G workgroups (k_draft_row streams it instead)
+// G workgroups (k_draft_row streams it instead).  ANY count, not only powers of two (round 4; the results do not depend on G):
+// B = 33 took G = 4 -- 132 workgroups on 256 CUs, 26.2 us with top-p -- where G = 7 takes 21.1; B = 65 ... 80 G = 2, 39 us, where
+// G = 3 takes 31.5 (profiles/r04_draft_groups.json: the time falls monotonically with G at every batch size measured).
 int choose_groups(int B, int n_tiles, int cus, bool have_ws) {
     int G = 1;
     if (have_ws && B <= kDgSlots / 2) {
-        int want = cus / (B > 0 ? B : 1);
-        while (G * 2 <= want && G * 2 <= kDgMaxGroups) G *= 2;
-        while (G > 1 && (static_cast<int64_t>(B) * G > kDgSlots || n_tiles / G < 8)) G >>= 1;
+        G = cus / (B > 0 ? B : 1);
+        if (G > kDgMaxGroups) G = kDgMaxGroups;
+        while (G > 1 && (static_cast<int64_t>(B) * G > kDgSlots || n_tiles / G < 8)) --G;
+        if (G < 1) G = 1;
     }
     if (g_debug_groups > 0 && have_ws && g_debug_groups <= kDgMaxGroups && static_cast<int64_t>(B) * g_debug_groups <= kDgSlots) G = g_debug_groups;
     return tiles_per_wave(n_tiles, G) <= 10 ? G : 0;

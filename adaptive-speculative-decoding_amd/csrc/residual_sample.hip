@@ -572,9 +572,10 @@ int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, in
         int G = 0;
         if (have_ws && g_debug_rs_groups >= 0 && B <= 64) {
             const int cus = current_device_cus();
-            G = 1;
-            while (G * 2 <= cus / B && G * 2 <= kDgMaxGroups) G *= 2;
-            while (G > 1 && (static_cast<int64_t>(B) * G > 256 || p.n_tiles / G < 8)) G >>= 1;
+            G = cus / B;                          // any count, not only powers of two (round 4: B = 33 ... 63 left half the CUs idle)
+            if (G > kDgMaxGroups) G = kDgMaxGroups;
+            while (G > 1 && (static_cast<int64_t>(B) * G > 256 || p.n_tiles / G < 8)) --G;
+            if (G < 1) G = 1;
             if (g_debug_rs_groups > 0 && g_debug_rs_groups <= kDgMaxGroups && static_cast<int64_t>(B) * g_debug_rs_groups <= 256) G = g_debug_rs_groups;
             const int tpw = ((p.n_tiles + G - 1) / G + kDrWaves - 1) / kDrWaves;
             if (tpw > 5) G = 0;
