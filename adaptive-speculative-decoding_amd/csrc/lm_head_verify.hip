@@ -547,6 +547,58 @@ __device__ __forceinline__ void tile_body(const LmHeadParams& p, unsigned char* 
         }
         return;
     }
+    if constexpr (WM == 1) {
+        // the "tall" form (ONE row block of 32 MT rows, eight wave columns of 32 NTW columns; asd_lm_head_verify for 256 < M <= 288):
+        // every wave folds its columns of every row, the eight partial records of a row meet in LDS and one thread per row merges
+        // them in wave order
+        constexpr int kRows = 32 * MT;
+        float* const meet8 = reinterpret_cast<float*>(lds);   // [8 wave columns][kRows][kMsg]  (the rings are idle now)
+        __syncthreads();                                       // the last superstage's fragment reads are done
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + 32 * mt + r;
+            const int tk = (wave_works && m < p.M && p.tok[m] >= p.v_offset) ? p.tok[m] - p.v_offset : -1;
+            float m2 = kSentinel, s = 0.0f, g = -INFINITY, bv = -INFINITY;
+            int bi = kNoIndex;
+            if (wave_works) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int n_first = n0 + 32 * NTW * wn + 32 * nt + 4 * h;
+                    if (p.need_argmax) fold_tile16<true>(acc[mt][nt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
+                    else fold_tile16<false>(acc[mt][nt], n_first, tk, p.V, p.c2, m2, s, g, bv, bi);
+                }
+            }
+            const float m2o = __shfl_xor(m2, 32, 64);          // the row's other columns of these tiles sit in lane r ^ 32
+            const float so = __shfl_xor(s, 32, 64);
+            const float go = __shfl_xor(g, 32, 64);
+            const float bvo = __shfl_xor(bv, 32, 64);
+            const int bio = __shfl_xor(bi, 32, 64);
+            ms_merge(m2, s, m2o, so);
+            g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));
+            if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+            if (h == 0) {
+                float* q = meet8 + (wn * kRows + 32 * mt + r) * kMsg;
+                q[0] = m2; q[1] = s; q[2] = g; q[3] = bv; q[4] = __int_as_float(bi);
+            }
+        }
+        __syncthreads();
+        if (t < kRows && m0 + t < p.M) {
+            float m2 = kSentinel, s = 0.0f, g = -INFINITY, bv = -INFINITY;
+            int bi = kNoIndex;
+            for (int w = 0; w < WN; ++w) {
+                const float* q = meet8 + (w * kRows + t) * kMsg;
+                ms_merge(m2, s, q[0], q[1]);
+                const float go = q[2];
+                g = (g != g) ? g : ((go != go) ? go : fmaxf(g, go));
+                const float bvo = q[3];
+                const int bio = __float_as_int(q[4]);
+                if (bvo > bv || (bvo == bv && bio < bi)) { bv = bvo; bi = bio; }
+            }
+            float* out = p.msg + (static_cast<int64_t>(p.unit0 + nb) * p.M + (m0 + t)) * kMsg;
+            out[0] = m2; out[1] = s; out[2] = g; out[3] = bv; out[4] = __int_as_float(bi);
+        }
+        return;
+    }
     float* const meet = reinterpret_cast<float*>(lds);   // [256 rows][kMsg]
     __syncthreads();                                      // the last superstage's fragment reads are done
     float tm2[2], ts[2], tg[2], tbv[2];
@@ -631,6 +683,15 @@ template <bool F16, int MT>
 __global__ __launch_bounds__(kThreads, 1) void k_linear_tall(LmHeadParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 256 * 128 + kHRing * 320 * 128];
     tile_body<1, (32 * MT + 63) / 64, F16, true, 1, MT, 2>(p, lds);
+}
+
+// asd_lm_head_verify, 256 < M <= 288 (B = 33 ... 36 at K = 8; K + 1 = 9 positions of 32 sequences): the same ONE row block with the
+// log-sum-exp epilogue -- a second row block would stream the whole matrix again for a handful of rows (72B head: 1 197 us at
+// M = 264 against 685 us at M = 256)
+template <bool F16, int MT>
+__global__ __launch_bounds__(kThreads, 1) void k_lm_head_tall(LmHeadParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 256 * 128 + kHRing * 320 * 128];
+    tile_body<1, (32 * MT + 63) / 64, F16, false, 1, MT, 2>(p, lds);
 }
 
 // ---- M > 256 rows (several row blocks share every weight tile): FOUR waves per workgroup, 128 x 128 logits per wave.
@@ -1276,6 +1337,19 @@ int lm_head_launch(const LmHeadCall& c) {
         p.n_blocks = static_cast<int>(blocks);
         if (f16) hipLaunchKernelGGL(k_lm_head_skinny<true>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, p);
         else hipLaunchKernelGGL(k_lm_head_skinny<false>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, p);
+        hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
+                           static_cast<int>(blocks), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
+                           c.lp_target, c.accept, c.n_acc, c.accept_bits, c.argmax_out, c.emit);
+        return launch_status();
+    }
+    if (M > kBM && M <= 288) {   // ONE tall row block (1 x 8 waves of 9 x 1 tiles) over every 256-column block
+        const int64_t blocks = (static_cast<int64_t>(c.V) + 255) / 256;
+        p.col0 = 0;
+        p.unit0 = 0;
+        p.m_blocks = 1;
+        p.n_blocks = static_cast<int>(blocks);
+        if (f16) hipLaunchKernelGGL((k_lm_head_tall<true, 9>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, p);
+        else hipLaunchKernelGGL((k_lm_head_tall<false, 9>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, p);
         hipLaunchKernelGGL(k_accept_from_blocks, dim3(c.B), dim3(64 * (c.K < 16 ? c.K : 16)), 0, st, p.msg,
                            static_cast<int>(blocks), c.lp_draft, c.u, c.tok, c.greedy ? 1 : 0, c.B, c.K, p.c2,
                            c.lp_target, c.accept, c.n_acc, c.accept_bits, c.argmax_out, c.emit);

@@ -100,6 +100,11 @@ def check(got, ref):
     (37, 8, 64, 300),        # ONE superstage; 296 rows: 40 real rows in the second block; ragged columns in both blocks
     (64, 8, 512, 2304),      # M = 512, nine full column blocks
     (96, 8, 1536, 256 * 100),         # m_blocks = 3, 300 tiles: more than one round of the CUs
+    # 256 < M <= 288 runs ONE tall row block (k_lm_head_tall: 1 x 8 waves of 9 x 1 tiles), eight wave columns merged through LDS
+    (33, 8, 128, 300),       # M = 264: eight real rows in the ninth tile; two column blocks, the last ragged (44 columns: waves 2..7 idle)
+    (36, 8, 512, 4173),      # M = 288 exactly; 17 column blocks, eight superstages
+    (32, 9, 192, 70000),     # K + 1 = 9 positions of 32 sequences; 274 column blocks (more than one round of the CUs), odd superstage count
+    (34, 8, 64, 257),        # ONE superstage; a single column in the second block
 ])
 def test_lm_head_verify_matches_oracle(B, K, D, V):
     case = make_case(B, K, D, V, seed=B * 1000 + K)
@@ -113,6 +118,7 @@ def test_lm_head_verify_matches_oracle(B, K, D, V):
     (32, 8, 4608, 65536 + 3 * 256 - 56),   # ... with reduction slices
     (128, 8, 256, 5000),      # the 4-wave kernel (M > 256)
     (37, 8, 64, 300),         # ... with a partial last row block
+    (35, 8, 256, 5000),       # the tall row block (256 < M <= 288)
 ])
 def test_lm_head_verify_f16_matches_oracle(B, K, D, V):
     """The same call on f16 hidden states and weights (ASD_DTYPE_F16: the reference loads its models in fp16,
@@ -159,7 +165,7 @@ def test_lm_head_verify_f16_matches_oracle(B, K, D, V):
 
 @pytest.mark.parametrize("B,K,D,V", [(3, 5, 64, 300), (8, 8, 256, 1000), (32, 8, 512, 4173), (40, 8, 128, 33000),
                                      (32, 8, 128, 66000), (32, 8, 4608, 65536 + 3 * 256 - 56), (16, 8, 192, 129),
-                                     (128, 8, 256, 5000), (37, 8, 64, 300)])
+                                     (128, 8, 256, 5000), (37, 8, 64, 300), (36, 8, 192, 3000)])
 def test_packed_weights_give_bit_identical_results(B, K, D, V):
     """asd_lm_head_pack_weights: the tile-major image (ld_w = 0) through every kernel variant -- skinny (M <= 64), wide and
     narrow blocks, two row blocks, split-K tail tiles -- returns exactly what the [V, D] matrix returns."""
