@@ -23,10 +23,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="8,16,24,32,40,48,64,96,128,192,256")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep_batch.json"))
+    ap.add_argument("--vocab", type=int, default=152064)
     ap.add_argument("--splits", default="0", help="forced split counts to time beside the heuristic (0), plain kernel only: e.g. 0,2,4")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    Kk, V = 8, 152064
+    Kk, V = 8, a.vocab
     lib = K._lib()
     packed = K.pack_mlp_weights(*predictor_weights(np), device=dev)
     Cc = torch.tensor(STAGE_COSTS, dtype=torch.float64, device=dev)
