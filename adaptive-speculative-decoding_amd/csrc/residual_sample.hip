@@ -570,7 +570,7 @@ int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, in
         const RgLayout l = rg_layout(B, static_cast<size_t>(p.n_tiles));
         const bool have_ws = workspace_bytes >= kWorkspaceHeaderBytes + l.legacy_bytes + l.small_bytes && p.n_tiles <= kDrMaxTiles;
         int G = 0;
-        if (have_ws && g_debug_rs_groups >= 0 && B <= 64) {
+        if (have_ws && g_debug_rs_groups >= 0 && B <= 128) {         // (B <= 128: two workgroups per sequence still fit the CUs)
             const int cus = current_device_cus();
             G = cus / B;                          // any count, not only powers of two (round 4: B = 33 ... 63 left half the CUs idle)
             if (G > kDgMaxGroups) G = kDgMaxGroups;
@@ -578,7 +578,7 @@ int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, in
             if (G < 1) G = 1;
             if (g_debug_rs_groups > 0 && g_debug_rs_groups <= kDgMaxGroups && static_cast<int64_t>(B) * g_debug_rs_groups <= 256) G = g_debug_rs_groups;
             const int tpw = ((p.n_tiles + G - 1) / G + kDrWaves - 1) / kDrWaves;
-            if (tpw > 5) G = 0;
+            if (tpw > 10) G = 0;
             if (G >= 1) {
                 RgParams q{};
                 q.r = p;
@@ -590,7 +590,9 @@ int residual_launch(const void* t_logits, int64_t ld_t, const void* d_logits, in
 #define ASD_LAUNCH_RG(DT)                                                                                 \
     do {                                                                                                  \
         if (tpw <= 3) hipLaunchKernelGGL((k_residual_group<DT, 3>), grid, block, 0, st, q);               \
-        else hipLaunchKernelGGL((k_residual_group<DT, 5>), grid, block, 0, st, q);                        \
+        else if (tpw <= 5) hipLaunchKernelGGL((k_residual_group<DT, 5>), grid, block, 0, st, q);          \
+        else if (tpw <= 7) hipLaunchKernelGGL((k_residual_group<DT, 7>), grid, block, 0, st, q);          \
+        else hipLaunchKernelGGL((k_residual_group<DT, 10>), grid, block, 0, st, q);                       \
     } while (0)
                 switch (dtype) {
                     case ASD_DTYPE_BF16: ASD_LAUNCH_RG(ASD_DTYPE_BF16); break;
